@@ -1,0 +1,838 @@
+// oracle_kat.cpp — known-answer tests that PIN oracle/rt_oracle.hpp.
+//
+// Every case below transcribes the VALUES (inputs and expected results) of one #[test] of the
+// reference (file:line cited per case); the tolerance is the reference's own assert_approx /
+// approximate PartialEq bar: |a - b| <= 1e-5.  Run by tests/test_oracle_kat.py; prints one
+// "PASS name" / "FAIL name" line per case and exits non-zero if any case failed.
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../oracle/rt_oracle.hpp"
+
+using namespace oracle;
+
+static int g_fail = 0, g_cases = 0;
+static bool g_case_ok = true;
+static const char* g_case = "";
+
+#define CHECK(...)                                                                           \
+    do {                                                                                     \
+        if (!(__VA_ARGS__)) {                                                                \
+            g_case_ok = false;                                                               \
+            std::printf("    check failed %s:%d: %s\n", __FILE__, __LINE__, #__VA_ARGS__);   \
+        }                                                                                    \
+    } while (0)
+#define CHECK_APPROX(a, b)                                                                         \
+    do {                                                                                           \
+        double _a = (a), _b = (b);                                                                 \
+        if (!approx(_a, _b)) {                                                                     \
+            g_case_ok = false;                                                                     \
+            std::printf("    approx failed %s:%d: %s = %.9g, want %.9g\n", __FILE__, __LINE__, #a, _a, _b); \
+        }                                                                                          \
+    } while (0)
+
+static void run(const char* name, const std::function<void()>& fn) {
+    g_case = name;
+    g_case_ok = true;
+    ++g_cases;
+    try {
+        fn();
+    } catch (const std::exception& e) {
+        g_case_ok = false;
+        std::printf("    exception: %s\n", e.what());
+    }
+    std::printf("%s %s\n", g_case_ok ? "PASS" : "FAIL", name);
+    if (!g_case_ok) ++g_fail;
+}
+
+static bool veq(const Vector& a, double x, double y, double z) { return a == Vector{x, y, z}; }
+static bool peq(const Point& a, double x, double y, double z) { return a == Point{x, y, z}; }
+static bool ceq(const Color& a, double r, double g, double b) { return a == Color{r, g, b}; }
+static Ray ray(double ox, double oy, double oz, double dx, double dy, double dz) {
+    return Ray{Point{ox, oy, oz}, Vector{dx, dy, dz}};
+}
+static const double S2 = std::sqrt(2.0);
+
+// world.rs:138-175
+static World test_world() {
+    Material m0;
+    m0.pattern = Pattern3D::Solid(Color{0.8, 1.0, 0.6});
+    m0.diffuse = 0.7;
+    m0.specular = 0.2;
+    World w;
+    w.objects.push_back(Shape::Sphere(ShapeBuilder{m0, Transform{}}));
+    w.objects.push_back(Shape::Sphere(ShapeBuilder{Material{}, Transform::scaling(0.5, 0.5, 0.5)}));
+    w.lights.push_back(Light::Point(PointLight{Point{-10, 10, -10}, color::WHITE}));
+    return w;
+}
+static Material glass_material() {  // intersection.rs:162-168
+    Material m;
+    m.index_of_refraction = 1.5;
+    m.transparency = 1.0;
+    return m;
+}
+static Shape glass_sphere() { return Shape::Sphere(ShapeBuilder{glass_material(), Transform{}}); }
+static Intersection ix(double t, const Shape& s) { return Intersection{t, &s}; }
+
+int main() {
+    // ------------------------------------------------------------------ float.rs:62-114
+    run("float.approx", [] {
+        CHECK(approx(3.14159, 3.141595));
+        CHECK(!approx(std::exp(1.0), M_PI));
+        CHECK(!approx(1.0, 1.0 + EPSILON + 1e-12));
+        CHECK(ge(1.00001, 1.0) && !ge(1.0, 1.00001) && ge(1.00001, 1.00001));  // float.rs:105-114
+    });
+
+    // ------------------------------------------------------------------ matrix.rs:458-587
+    run("matrix.determinant_4x4", [] {
+        Matrix4 m{{{-2, -8, 3, 5}, {-3, 1, 7, 3}, {1, 2, -9, 6}, {-6, 7, 7, -9}}};
+        CHECK_APPROX(m.cofactor(0, 0), 690.0);
+        CHECK_APPROX(m.cofactor(0, 1), 447.0);
+        CHECK_APPROX(m.cofactor(0, 2), 210.0);
+        CHECK_APPROX(m.cofactor(0, 3), 51.0);
+        CHECK_APPROX(m.determinant(), -4071.0);
+    });
+    run("matrix.inverse_1", [] {
+        Matrix4 m{{{-5, 2, 6, -8}, {1, -5, 1, 8}, {7, 7, -6, -7}, {1, -3, 7, 4}}};
+        Matrix4 inv{};
+        CHECK(m.try_inverse(inv));
+        CHECK_APPROX(m.determinant(), 532.0);
+        CHECK_APPROX(m.cofactor(2, 3), -160.0);
+        CHECK_APPROX(inv.m[3][2], -160.0 / 532.0);
+        CHECK_APPROX(m.cofactor(3, 2), 105.0);
+        CHECK_APPROX(inv.m[2][3], 105.0 / 532.0);
+        Matrix4 want{{{0.21805, 0.45113, 0.24060, -0.04511},
+                      {-0.80827, -1.45677, -0.44361, 0.52068},
+                      {-0.07895, -0.22368, -0.05263, 0.19737},
+                      {-0.52256, -0.81391, -0.30075, 0.30639}}};
+        CHECK(inv == want);
+    });
+    run("matrix.inverse_2_3", [] {
+        Matrix4 m{{{8, -5, 9, 2}, {7, 5, 6, 1}, {-6, 0, 9, 6}, {-3, 0, -9, -4}}};
+        Matrix4 inv{};
+        CHECK(m.try_inverse(inv));
+        Matrix4 want{{{-0.15385, -0.15385, -0.28205, -0.53846},
+                      {-0.07692, 0.12308, 0.02564, 0.03077},
+                      {0.35897, 0.35897, 0.43590, 0.92308},
+                      {-0.69231, -0.69231, -0.76923, -1.92308}}};
+        CHECK(inv == want);
+        Matrix4 m3{{{9, 3, 0, 9}, {-5, -2, -6, -3}, {-4, 9, 6, 4}, {-7, 6, 6, 2}}};
+        Matrix4 want3{{{-0.04074, -0.07778, 0.14444, -0.22222},
+                       {-0.07778, 0.03333, 0.36667, -0.33333},
+                       {-0.02901, -0.14630, -0.10926, 0.12963},
+                       {0.17778, 0.06667, -0.26667, 0.33333}}};
+        CHECK(m3.try_inverse(inv));
+        CHECK(inv == want3);
+        Matrix4 zero{};
+        CHECK(!zero.try_inverse(inv));  // matrix.rs:522-526
+    });
+    run("matrix.product_times_inverse", [] {
+        Matrix4 m0{{{3, -9, 7, 3}, {3, -8, 2, -9}, {-4, 4, 4, 1}, {-6, 5, -1, 1}}};
+        Matrix4 m1{{{8, 2, 2, 2}, {3, -1, 7, 0}, {7, 0, 5, 4}, {6, -2, 0, 5}}};
+        Matrix4 inv{};
+        CHECK(m1.try_inverse(inv));
+        CHECK((m0 * m1) * inv == m0);
+    });
+
+    // ------------------------------------------------------------------ transform.rs:324-632
+    run("transform.basic", [] {
+        CHECK(peq(Transform::translation(5, -3, 2) * Point{-3, 4, 5}, 2, 1, 7));            // :324-330
+        CHECK(peq(Transform::translation(5, -3, 2).inverse() * Point{-3, 4, 5}, -8, 7, 3));  // :332-339
+        CHECK(veq(Transform::translation(5, -3, 2) * Vector{-3, 4, 5}, -3, 4, 5));           // :341-347
+        CHECK(peq(Transform::scaling(2, 3, 4) * Point{-4, 6, 8}, -8, 18, 32));               // :349-355
+        CHECK(veq(Transform::scaling(2, 3, 4).inverse() * Vector{-4, 6, 8}, -2, 2, 2));      // :365-372
+        bool threw = false;
+        try {
+            Transform::scaling(0, 1, 1);
+        } catch (const Error&) {
+            threw = true;
+        }
+        CHECK(threw);  // :374-386
+    });
+    run("transform.rotations", [] {
+        CHECK(peq(Transform::rotation_x(M_PI / 4) * Point{0, 1, 0}, 0, S2 / 2, S2 / 2));  // :406-417
+        CHECK(peq(Transform::rotation_x(M_PI / 2) * Point{0, 1, 0}, 0, 0, 1));
+        CHECK(peq(Transform::rotation_x(M_PI / 4).inverse() * Point{0, 1, 0}, 0, S2 / 2, -S2 / 2));  // :420-430
+        CHECK(peq(Transform::rotation_y(M_PI / 4) * Point{0, 0, 1}, S2 / 2, 0, S2 / 2));             // :433-444
+        CHECK(peq(Transform::rotation_y(M_PI / 2) * Point{0, 0, 1}, 1, 0, 0));
+        CHECK(peq(Transform::rotation_z(M_PI / 4) * Point{0, 1, 0}, -S2 / 2, S2 / 2, 0));  // :447-458
+        CHECK(peq(Transform::rotation_z(M_PI / 2) * Point{0, 1, 0}, -1, 0, 0));
+    });
+    run("transform.shearing", [] {  // :461-528
+        Point p{2, 3, 4};
+        CHECK(peq(Transform::shearing(1, 0, 0, 0, 0, 0) * p, 5, 3, 4));
+        CHECK(peq(Transform::shearing(0, 1, 0, 0, 0, 0) * p, 6, 3, 4));
+        CHECK(peq(Transform::shearing(0, 0, 1, 0, 0, 0) * p, 2, 5, 4));
+        CHECK(peq(Transform::shearing(0, 0, 0, 1, 0, 0) * p, 2, 7, 4));
+        CHECK(peq(Transform::shearing(0, 0, 0, 0, 1, 0) * p, 2, 3, 6));
+        CHECK(peq(Transform::shearing(0, 0, 0, 0, 0, 1) * p, 2, 3, 7));
+        bool threw = false;
+        try {
+            Transform::shearing(1.0, 2.0, 1.0, 2.0, 0.0, 0.0);
+        } catch (const Error&) {
+            threw = true;
+        }
+        CHECK(threw);
+    });
+    run("transform.chaining", [] {  // :531-558
+        Transform t0 = Transform::rotation_x(M_PI / 2), t1 = Transform::scaling(5, 5, 5),
+                  t2 = Transform::translation(10, 5, 7);
+        Point p1 = t0 * Point{1, 0, 1};
+        CHECK(peq(p1, 1, -1, 0));
+        CHECK(peq(t1 * p1, 5, -5, 0));
+        CHECK(peq(t2 * (t1 * p1), 15, 0, 7));
+        CHECK(peq((t2 * t1 * t0) * Point{1, 0, 1}, 15, 0, 7));
+    });
+    run("transform.view", [] {  // :583-632
+        CHECK(Transform::view(Point{0, 0, 0}, Point{0, 0, -1}, Vector{0, 1, 0}) == Transform{});
+        CHECK(Transform::view(Point{0, 0, 0}, Point{0, 0, 1}, Vector{0, 1, 0}) == Transform::scaling(-1, 1, -1));
+        CHECK(Transform::view(Point{0, 0, 8}, Point{0, 0, 0}, Vector{0, 1, 0}) == Transform::translation(0, 0, -8));
+        Transform t = Transform::view(Point{1, 3, 2}, Point{4, -2, 8}, Vector{1, 1, 0});
+        Matrix4 want{{{-0.50709, 0.50709, 0.67612, -2.36643},
+                      {0.76772, 0.60609, 0.12122, -2.82843},
+                      {-0.35857, 0.59761, -0.71714, 0.0},
+                      {0, 0, 0, 1}}};
+        CHECK(t.mat == want);
+    });
+
+    // ------------------------------------------------------------------ tuple.rs (reflect/normalize)
+    run("tuple.reflect_normalize", [] {
+        CHECK(veq(Vector{1, -1, 0}.reflect(Vector{0, 1, 0}), 1, 1, 0));
+        CHECK(veq(Vector{0, -1, 0}.reflect(Vector{S2 / 2, S2 / 2, 0}), 1, 0, 0));
+        CHECK(veq(Vector{1, 2, 3}.normalize(), 0.26726, 0.53452, 0.80178));
+        CHECK_APPROX((Vector{1, 2, 3}.magnitude()), std::sqrt(14.0));
+        Vector out;
+        CHECK(!Vector{0, 0, 0}.try_normalize(out));
+        CHECK(veq(Vector{1, 2, 3}.cross(Vector{2, 3, 4}), -1, 2, -1));
+    });
+
+    // ------------------------------------------------------------------ camera.rs:258-361
+    run("camera.pixel_size", [] {
+        CHECK_APPROX(Camera::try_from(CameraBuilder{200, 125, M_PI / 2, Transform{}}).pixel_size, 0.01);
+        CHECK_APPROX(Camera::try_from(CameraBuilder{125, 200, M_PI / 2, Transform{}}).pixel_size, 0.01);
+    });
+    run("camera.rays", [] {
+        Camera c = Camera::try_from(CameraBuilder{201, 101, M_PI / 2, Transform{}});
+        Ray r = c.ray_for_pixel(100, 50);
+        CHECK(peq(r.origin, 0, 0, 0) && veq(r.direction, 0, 0, -1));
+        r = c.ray_for_pixel(0, 0);
+        CHECK(peq(r.origin, 0, 0, 0) && veq(r.direction, 0.66519, 0.33259, -0.66851));
+        Camera c2 = Camera::try_from(
+            CameraBuilder{201, 101, M_PI / 2, Transform::rotation_y(M_PI / 4) * Transform::translation(0, -2, 5)});
+        r = c2.ray_for_pixel(100, 50);
+        CHECK(peq(r.origin, 0, 2, -5) && veq(r.direction, S2 / 2, 0, -S2 / 2));
+    });
+    run("camera.errors", [] {  // camera.rs:393-431
+        int threw = 0;
+        for (double fov : {0.0, M_PI, 3.0 * M_PI}) try {
+                Camera::try_from(CameraBuilder{100, 200, fov, Transform{}});
+            } catch (const Error&) {
+                ++threw;
+            }
+        try {
+            Camera::try_from(CameraBuilder{0, 0, M_PI / 2, Transform{}});
+        } catch (const Error&) {
+            ++threw;
+        }
+        CHECK(threw == 4);
+    });
+    run("camera.render_11x11", [] {  // camera.rs:336-361 — the one end-to-end pin
+        World w = test_world();
+        Camera c = Camera::try_from(
+            CameraBuilder{11, 11, M_PI / 2, Transform::view(Point{0, 0, -5}, Point{0, 0, 0}, Vector{0, 1, 0})});
+        Canvas img = c.render(w);
+        CHECK(ceq(img.pixel_at(5, 5), 0.38066, 0.47583, 0.2855));
+    });
+
+    // ------------------------------------------------------------------ canvas.rs:76-106
+    run("canvas.quantize", [] {
+        CHECK(quantize_u8(1.5) == 255 && quantize_u8(0.5) == 127 && quantize_u8(-0.5) == 0);
+        CHECK(quantize_u8(1.0) == 255 && quantize_u8(0.0) == 0 && quantize_u8(std::nan("")) == 0);
+    });
+
+    // ------------------------------------------------------------------ sphere.rs:86-166, shape.rs:147-205
+    run("sphere.intersections", [] {
+        Shape s = Shape::Sphere();
+        auto xs = s.intersect(ray(0, 0, -5, 0, 0, 1));
+        CHECK(xs.size() == 2);
+        CHECK_APPROX(xs[0].t, 4.0);
+        CHECK_APPROX(xs[1].t, 6.0);
+        xs = s.intersect(ray(0, 1, -5, 0, 0, 1));
+        CHECK(xs.size() == 2);
+        CHECK_APPROX(xs[0].t, 5.0);
+        CHECK_APPROX(xs[1].t, 5.0);
+        CHECK(s.intersect(ray(0, 2, -5, 0, 0, 1)).empty());
+        xs = s.intersect(ray(0, 0, 0, 0, 0, 1));
+        CHECK_APPROX(xs[0].t, -1.0);
+        CHECK_APPROX(xs[1].t, 1.0);
+        xs = s.intersect(ray(0, 0, 5, 0, 0, 1));
+        CHECK_APPROX(xs[0].t, -6.0);
+        CHECK_APPROX(xs[1].t, -4.0);
+    });
+    run("shape.object_ray_and_world_normal", [] {
+        Ray r = ray(0, 0, -5, 0, 0, 1).transform(Transform::scaling(2, 2, 2).inverse());
+        CHECK(peq(r.origin, 0, 0, -2.5) && veq(r.direction, 0, 0, 0.5));
+        r = ray(0, 0, -5, 0, 0, 1).transform(Transform::translation(5, 0, 0).inverse());
+        CHECK(peq(r.origin, -5, 0, -5) && veq(r.direction, 0, 0, 1));
+        Shape s1 = Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(0, 1, 0)});
+        CHECK(veq(s1.normal_at(Point{0, 1.70711, -0.70711}, Intersection{}), 0, 0.70711, -0.70711));
+        Shape s2 = Shape::Sphere(ShapeBuilder{Material{}, Transform::scaling(1, 0.5, 1) * Transform::rotation_z(M_PI / 5)});
+        CHECK(veq(s2.normal_at(Point{0, S2 / 2, -S2 / 2}, Intersection{}), 0, 0.97014, -0.24254));
+    });
+    run("shape.parent_space_bbox", [] {  // shape.rs:249-260
+        Shape s = Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(1, -3, 5) * Transform::scaling(0.5, 2, 4)});
+        CHECK(peq(s.cache.parent_space_bounding_box.min, 0.5, -5, 1));
+        CHECK(peq(s.cache.parent_space_bounding_box.max, 1.5, -1, 9));
+    });
+    run("shape.normal_on_child_object", [] {  // shape.rs:208-246
+        Group inner = Group::from(GroupBuilder{{}, Transform::scaling(1, 2, 3)});
+        inner.push(Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(5, 0, 0)}));
+        Group outer = Group::from(GroupBuilder{{}, Transform::rotation_y(M_PI / 2)});
+        outer.push(Shape::Group(inner));
+        const Shape& child = outer.children[0].children[0];
+        CHECK(veq(child.normal_at(Point{1.7321, 1.1547, -5.5774}, Intersection{0.0, &child}), 0.2857, 0.42854, -0.85716));
+    });
+
+    // ------------------------------------------------------------------ plane.rs:65-137
+    run("plane", [] {
+        Shape p = Shape::Plane();
+        CHECK(p.intersect(ray(0, 10, 0, 0, 0, 1)).empty());
+        CHECK(p.intersect(ray(0, 0, 0, 0, 0, 1)).empty());
+        auto xs = p.intersect(ray(0, 1, 0, 0, -1, 0));
+        CHECK(xs.size() == 1);
+        CHECK_APPROX(xs[0].t, 1.0);
+        xs = p.intersect(ray(0, -1, 0, 0, 1, 0));
+        CHECK(xs.size() == 1);
+        CHECK_APPROX(xs[0].t, 1.0);
+        CHECK(veq(p.local_normal_at(Point{10, 0, -10}, Intersection{}), 0, 1, 0));
+        CHECK(std::isinf(p.cache.bounding_box.min.x) && p.cache.bounding_box.min.y == 0.0);
+    });
+
+    // ------------------------------------------------------------------ cube.rs:151-368
+    run("cube.intersections", [] {
+        Shape c = Shape::Cube();
+        const double rays[7][6] = {{5, 0.5, 0, -1, 0, 0}, {-5, 0.5, 0, 1, 0, 0}, {0.5, 5, 0, 0, -1, 0}, {0.5, -5, 0, 0, 1, 0},
+                                   {0.5, 0, 5, 0, 0, -1}, {0.5, 0, -5, 0, 0, 1}, {0, 0.5, 0, 0, 0, 1}};
+        const double want[7][2] = {{4, 6}, {4, 6}, {4, 6}, {4, 6}, {4, 6}, {4, 6}, {-1, 1}};
+        for (int i = 0; i < 7; ++i) {
+            auto xs = c.intersect(ray(rays[i][0], rays[i][1], rays[i][2], rays[i][3], rays[i][4], rays[i][5]));
+            CHECK(xs.size() == 2);
+            if (xs.size() == 2) {
+                CHECK_APPROX(xs[0].t, want[i][0]);
+                CHECK_APPROX(xs[1].t, want[i][1]);
+            }
+        }
+        const double miss[6][6] = {{-2, 0, 0, 0.2673, 0.5345, 0.8018}, {0, -2, 0, 0.8018, 0.2673, 0.5345},
+                                   {0, 0, -2, 0.5345, 0.8018, 0.2673}, {2, 0, 2, 0, 0, -1},
+                                   {0, 2, 2, 0, -1, 0},               {2, 2, 0, -1, 0, 0}};
+        for (const auto& m : miss) CHECK(c.intersect(ray(m[0], m[1], m[2], m[3], m[4], m[5])).empty());
+    });
+    run("cube.normals", [] {
+        Shape c = Shape::Cube();
+        Intersection none{};
+        CHECK(veq(c.local_normal_at(Point{1, 0.5, -0.8}, none), 1, 0, 0));
+        CHECK(veq(c.local_normal_at(Point{-1, -0.2, 0.9}, none), -1, 0, 0));
+        CHECK(veq(c.local_normal_at(Point{-0.4, 1, -0.1}, none), 0, 1, 0));
+        CHECK(veq(c.local_normal_at(Point{0.3, -1, -0.7}, none), 0, -1, 0));
+        CHECK(veq(c.local_normal_at(Point{-0.6, 0.3, 1}, none), 0, 0, 1));
+        CHECK(veq(c.local_normal_at(Point{0.4, 0.4, -1}, none), 0, 0, -1));
+        CHECK(veq(c.local_normal_at(Point{1, 1, 1}, none), 1, 0, 0));
+        CHECK(veq(c.local_normal_at(Point{-1, -1, -1}, none), -1, 0, 0));
+    });
+
+    // ------------------------------------------------------------------ cylinder.rs:234-595
+    run("cylinder.unbounded", [] {
+        Shape c = Shape::Cylinder();
+        CHECK(c.intersect(ray(1, 0, 0, 0, 1, 0)).empty());
+        CHECK(c.intersect(ray(0, 0, 0, 0, 1, 0)).empty());
+        CHECK(c.intersect(ray(0, 0, -5, 1, 1, 1)).empty());
+        auto xs = c.intersect(ray(1, 0, -5, 0, 0, 1));
+        CHECK_APPROX(xs.at(0).t, 5.0);
+        CHECK_APPROX(xs.at(1).t, 5.0);
+        xs = c.intersect(ray(0, 0, -5, 0, 0, 1));
+        CHECK_APPROX(xs.at(0).t, 4.0);
+        CHECK_APPROX(xs.at(1).t, 6.0);
+        Vector d = Vector{0.1, 1, 1}.normalize();
+        xs = c.intersect(Ray{Point{0.5, 0, -5}, d});
+        CHECK_APPROX(xs.at(0).t, 6.80798);
+        CHECK_APPROX(xs.at(1).t, 7.08872);
+        Intersection none{};
+        CHECK(veq(c.local_normal_at(Point{1, 0, 0}, none), 1, 0, 0));
+        CHECK(veq(c.local_normal_at(Point{0, 5, -1}, none), 0, 0, -1));
+        CHECK(veq(c.local_normal_at(Point{0, -2, 1}, none), 0, 0, 1));
+        CHECK(veq(c.local_normal_at(Point{-1, 1, 0}, none), -1, 0, 0));
+        CHECK(c.cyl_min == -INF && c.cyl_max == INF && !c.closed);
+    });
+    run("cylinder.constrained_and_caps", [] {
+        CylinderBuilder b;
+        b.min = 1.0, b.max = 2.0;
+        Shape c = Shape::Cylinder(b);
+        CHECK(c.intersect(ray(0, 1.5, 0, 0.1, 1, 0)).empty());
+        CHECK(c.intersect(ray(0, 3, -5, 0, 0, 1)).empty());
+        CHECK(c.intersect(ray(0, 0, -5, 0, 0, 1)).empty());
+        CHECK(c.intersect(ray(0, 2, -5, 0, 0, 1)).empty());
+        CHECK(c.intersect(ray(0, 1, -5, 0, 0, 1)).empty());
+        CHECK(c.intersect(ray(0, 1.5, -2, 0, 0, 1)).size() == 2);
+        b.closed = true;
+        Shape cc = Shape::Cylinder(b);
+        CHECK(cc.intersect(ray(0, 3, 0, 0, -1, 0)).size() == 2);
+        CHECK(cc.intersect(ray(0, 3, -2, 0, -1, 2)).size() == 2);
+        CHECK(cc.intersect(ray(0, 0, -2, 0, 1, 2)).size() == 2);
+        CHECK(cc.intersect(ray(0, 4, -2, 0, -1, 1)).size() == 2);
+        CHECK(cc.intersect(ray(0, -1, -2, 0, 1, 1)).size() == 2);
+        Intersection none{};
+        CHECK(veq(cc.local_normal_at(Point{0, 1, 0}, none), 0, -1, 0));
+        CHECK(veq(cc.local_normal_at(Point{0.5, 1, 0}, none), 0, -1, 0));
+        CHECK(veq(cc.local_normal_at(Point{0, 1, 0.5}, none), 0, -1, 0));
+        CHECK(veq(cc.local_normal_at(Point{0, 2, 0}, none), 0, 1, 0));
+        CHECK(veq(cc.local_normal_at(Point{0.5, 2, 0}, none), 0, 1, 0));
+        CHECK(veq(cc.local_normal_at(Point{0, 2, 0.5}, none), 0, 1, 0));
+        CylinderBuilder b2;
+        b2.min = -5, b2.max = 3;
+        Shape c2 = Shape::Cylinder(b2);
+        CHECK(peq(c2.cache.bounding_box.min, -1, -5, -1) && peq(c2.cache.bounding_box.max, 1, 3, 1));
+    });
+
+    // ------------------------------------------------------------------ triangle.rs:147-338, smooth_triangle.rs:60-110
+    run("triangle", [] {
+        TriangleBuilder tb{Material{}, {Point{0, 1, 0}, Point{-1, 0, 0}, Point{1, 0, 0}}};
+        Shape t = Shape::Triangle(tb);
+        CHECK(veq(t.e0, -1, -1, 0) && veq(t.e1, 1, -1, 0) && veq(t.normal, 0, 0, -1));
+        CHECK(t.intersect(ray(0, -1, -2, 0, 1, 0)).empty());
+        CHECK(t.intersect(ray(1, 1, -2, 0, 0, 1)).empty());
+        CHECK(t.intersect(ray(-1, 1, -2, 0, 0, 1)).empty());
+        CHECK(t.intersect(ray(0, -1, -2, 0, 0, 1)).empty());
+        auto xs = t.intersect(ray(0, 0.5, -2, 0, 0, 1));
+        CHECK(xs.size() == 1);
+        CHECK_APPROX(xs.at(0).t, 2.0);
+        bool threw = false;
+        try {
+            Shape::Triangle(TriangleBuilder{Material{}, {Point{1, 0, 0}, Point{2, 1, 0}, Point{1, 0, 0}}});
+        } catch (const Error&) {
+            threw = true;
+        }
+        CHECK(threw);
+        Shape t2 = Shape::Triangle(TriangleBuilder{Material{}, {Point{-3, 7, 2}, Point{6, 2, -4}, Point{2, -1, -1}}});
+        CHECK(peq(t2.cache.bounding_box.min, -3, -1, -4) && peq(t2.cache.bounding_box.max, 6, 7, 2));
+    });
+    run("smooth_triangle", [] {
+        TriangleBuilder tb{Material{}, {Point{0, 1, 0}, Point{-1, 0, 0}, Point{1, 0, 0}}};
+        Shape t = Shape::SmoothTriangle(tb, Vector{0, 1, 0}, Vector{-1, 0, 0}, Vector{1, 0, 0});
+        auto xs = t.intersect(ray(-0.2, 0.3, -2, 0, 0, 1));
+        CHECK(xs.size() == 1 && xs[0].has_uv);
+        CHECK_APPROX(xs.at(0).u, 0.45);
+        CHECK_APPROX(xs.at(0).v, 0.25);
+        Intersection i{1.0, &t, true, 0.45, 0.25};
+        CHECK(veq(t.normal_at(Point{0, 0, 0}, i), -0.5547, 0.83205, 0));
+        Computation comps = prepare_computation(i, ray(-0.2, 0.3, -2, 0, 0, 1), {i});
+        CHECK(veq(comps.normalv, -0.5547, 0.83205, 0));
+    });
+
+    // ------------------------------------------------------------------ bounding_box.rs:156-456
+    run("bbox.add_merge_contains", [] {
+        BoundingBox b;
+        b.add(Point{-5, 2, 0});
+        b.add(Point{7, 0, -3});
+        CHECK(peq(b.min, -5, 0, -3) && peq(b.max, 7, 2, 0));
+        BoundingBox b0{Point{-5, -2, 0}, Point{7, 4, 4}};
+        b0.merge(BoundingBox{Point{8, -7, -2}, Point{14, 2, 8}});
+        CHECK(peq(b0.min, -5, -7, -2) && peq(b0.max, 14, 4, 8));
+        BoundingBox bb{Point{5, -2, 0}, Point{11, 4, 7}};
+        CHECK(bb.contains_point(Point{5, -2, 0}) && bb.contains_point(Point{11, 4, 7}) && bb.contains_point(Point{8, 1, 3}));
+        CHECK(!bb.contains_point(Point{3, 0, 3}) && !bb.contains_point(Point{8, -4, 3}) && !bb.contains_point(Point{8, 1, -1}));
+        CHECK(!bb.contains_point(Point{13, 1, 3}) && !bb.contains_point(Point{8, 5, 3}) && !bb.contains_point(Point{8, 1, 8}));
+        CHECK(bb.contains(BoundingBox{Point{5, -2, 0}, Point{11, 4, 7}}));
+        CHECK(bb.contains(BoundingBox{Point{6, -1, 1}, Point{10, 3, 6}}));
+        CHECK(!bb.contains(BoundingBox{Point{4, -3, -1}, Point{10, 3, 6}}));
+        CHECK(!bb.contains(BoundingBox{Point{6, -1, 1}, Point{12, 5, 8}}));
+    });
+    run("bbox.transform", [] {
+        BoundingBox b{Point{-1, -1, -1}, Point{1, 1, 1}};
+        BoundingBox t = b.transform(Transform::rotation_x(M_PI / 4) * Transform::rotation_y(M_PI / 4));
+        CHECK(peq(t.min, -1.41421, -1.7071, -1.7071) && peq(t.max, 1.41421, 1.7071, 1.7071));
+    });
+    run("bbox.intersect", [] {
+        BoundingBox b{Point{-1, -1, -1}, Point{1, 1, 1}};
+        const double hit[7][6] = {{5, 0.5, 0, -1, 0, 0}, {-5, 0.5, 0, 1, 0, 0}, {0.5, 5, 0, 0, -1, 0}, {0.5, -5, 0, 0, 1, 0},
+                                  {0.5, 0, 5, 0, 0, -1}, {0.5, 0, -5, 0, 0, 1}, {0, 0.5, 0, 0, 0, 1}};
+        for (const auto& h : hit) CHECK(b.intersect(ray(h[0], h[1], h[2], h[3], h[4], h[5])));
+        const double miss[6][6] = {{-2, 0, 0, 2, 4, 6}, {0, -2, 0, 6, 2, 4}, {0, 0, -2, 4, 6, 2},
+                                   {2, 0, 2, 0, 0, -1}, {0, 2, 2, 0, -1, 0}, {2, 2, 0, -1, 0, 0}};
+        for (const auto& m : miss) CHECK(!b.intersect(ray(m[0], m[1], m[2], m[3], m[4], m[5])));
+        BoundingBox n{Point{5, -2, 0}, Point{11, 4, 7}};
+        const double hit2[7][6] = {{5, 1, 2, 1, 0, 0},   {-5, -1, 4, 1, 0, 0}, {7, 6, 5, 0, -1, 0}, {9, -5, 6, 0, 1, 0},
+                                   {8, 2, 12, 0, 0, -1}, {6, 0, -5, 0, 0, 1},  {8, 1, 3.5, 0, 0, 1}};
+        for (const auto& h : hit2) CHECK(n.intersect(ray(h[0], h[1], h[2], h[3], h[4], h[5])));
+        const double miss2[6][6] = {{9, -1, -8, 2, 4, 6}, {8, 3, -4, 6, 2, 4},  {9, -1, -2, 4, 6, 2},
+                                    {4, 0, 9, 0, 0, -1},  {8, 6, -1, 0, -1, 0}, {12, 5, 4, -1, 0, 0}};
+        for (const auto& m : miss2) CHECK(!n.intersect(ray(m[0], m[1], m[2], m[3], m[4], m[5])));
+    });
+    run("bbox.split", [] {
+        BoundingBox l, r;
+        BoundingBox{Point{-1, -4, -5}, Point{9, 6, 5}}.split(l, r);
+        CHECK(peq(l.min, -1, -4, -5) && peq(l.max, 4, 6, 5) && peq(r.min, 4, -4, -5) && peq(r.max, 9, 6, 5));
+        BoundingBox{Point{-1, -2, -3}, Point{9, 5.5, 3}}.split(l, r);
+        CHECK(peq(l.max, 4, 5.5, 3) && peq(r.min, 4, -2, -3));
+        BoundingBox{Point{-1, -2, -3}, Point{5, 8, 3}}.split(l, r);
+        CHECK(peq(l.max, 5, 3, 3) && peq(r.min, -1, 3, -3));
+        BoundingBox{Point{-1, -2, -3}, Point{5, 3, 7}}.split(l, r);
+        CHECK(peq(l.max, 5, 3, 2) && peq(r.min, -1, -2, 2));
+    });
+
+    // ------------------------------------------------------------------ group.rs:260-440
+    run("group.intersect", [] {
+        Group empty;
+        CHECK(Shape::Group(empty).intersect(ray(0, 0, 0, 0, 0, 1)).empty());
+        Group g;
+        g.push(Shape::Sphere());
+        g.push(Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(0, 0, -3)}));
+        g.push(Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(5, 0, 0)}));
+        Shape gs = Shape::Group(g);
+        auto xs = gs.intersect(ray(0, 0, -5, 0, 0, 1));
+        CHECK(xs.size() == 4);
+        if (xs.size() == 4) {
+            CHECK(xs[0].object == &gs.children[1] && xs[1].object == &gs.children[1]);
+            CHECK(xs[2].object == &gs.children[0] && xs[3].object == &gs.children[0]);
+        }
+        Group tg = Group::from(GroupBuilder{{Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(5, 0, 0)})},
+                                            Transform::scaling(2, 2, 2)});
+        CHECK(Shape::Group(tg).intersect(ray(10, 0, -10, 0, 0, 1)).size() == 2);
+    });
+    run("group.bounding_box", [] {
+        CylinderBuilder cb;
+        cb.transform = Transform::translation(-4, -1, 4) * Transform::scaling(0.5, 1, 0.5);
+        cb.min = -2, cb.max = 2;
+        Group g = Group::from(GroupBuilder{
+            {Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(2, 5, -3) * Transform::scaling(2, 2, 2)}),
+             Shape::Cylinder(cb)},
+            Transform::scaling(2, 2, 2)});
+        BoundingBox bb = g.bounding_box();
+        CHECK(peq(bb.min, -9, -6, -10) && peq(bb.max, 8, 14, 9));
+    });
+    run("group.partition_and_divide", [] {
+        Shape s0 = Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(-2, 0, 0)});
+        Shape s1 = Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(2, 0, 0)});
+        Shape s2 = Shape::Sphere();
+        Group g;
+        g.push(s0), g.push(s1), g.push(s2);
+        std::vector<Shape> l, r;
+        g.partition_children(l, r);
+        CHECK(g.children.size() == 1 && g.children[0] == s2);
+        CHECK(l.size() == 1 && l[0] == s0 && r.size() == 1 && r[0] == s1);
+        Group m;
+        std::vector<Shape> two{Shape::Sphere(), Shape::Sphere()};
+        m.make_subgroup(two);
+        CHECK(m.children.size() == 1 && m.children[0].kind == Shape::GROUP && m.children[0].children.size() == 2);
+        Shape s4 = Shape::Sphere(ShapeBuilder{Material{}, Transform::scaling(4, 4, 4)});
+        Group d = Group::from(GroupBuilder{{s0, s1, s4}, Transform{}});
+        d.divide(1);
+        CHECK(d.children.size() == 3 && d.children[0] == s4);
+        CHECK(d.children[1].kind == Shape::GROUP && d.children[1].children.size() == 1 && d.children[1].children[0] == s0);
+        CHECK(d.children[2].kind == Shape::GROUP && d.children[2].children.size() == 1 && d.children[2].children[0] == s1);
+    });
+
+    // ------------------------------------------------------------------ intersection.rs:210-668
+    run("intersection.hit_and_sort", [] {
+        Shape o = glass_sphere();
+        std::vector<Intersection> xs{ix(1, o), ix(2, o)};
+        Intersection h;
+        CHECK(hit_of(xs, h) && h.t == 1.0);
+        xs = {ix(-1, o), ix(1, o)};
+        CHECK(hit_of(xs, h) && h.t == 1.0);
+        xs = {ix(-2, o), ix(-1, o)};
+        CHECK(!hit_of(xs, h));
+        xs = {ix(5, o), ix(7, o), ix(-3, o), ix(2, o)};
+        sort_intersections(xs);
+        CHECK(xs[0].t == -3 && xs[1].t == 2 && xs[2].t == 5 && xs[3].t == 7);
+        xs = {ix(5, o), ix(7, o), ix(-3, o), ix(2, o)};
+        CHECK(hit_of(xs, h) && h.t == 2.0);
+    });
+    run("intersection.prepare", [] {
+        Shape o = glass_sphere();
+        Intersection i = ix(4, o);
+        Computation c = prepare_computation(i, ray(0, 0, -5, 0, 0, 1), {i});
+        CHECK(peq(c.point, 0, 0, -1) && veq(c.eyev, 0, 0, -1) && veq(c.normalv, 0, 0, -1) && !c.inside);
+        i = ix(1, o);
+        c = prepare_computation(i, ray(0, 0, 0, 0, 0, 1), {i});
+        CHECK(peq(c.point, 0, 0, 1) && veq(c.eyev, 0, 0, -1) && c.inside && veq(c.normalv, 0, 0, -1));
+        Shape t = Shape::Sphere(ShapeBuilder{glass_material(), Transform::translation(0, 0, 1)});
+        i = ix(5, t);
+        c = prepare_computation(i, ray(0, 0, -5, 0, 0, 1), {i});
+        CHECK(c.over_point.z < -EPSILON / 2.0 && c.point.z > c.over_point.z);
+        CHECK(c.under_point.z > EPSILON / 2.0 && c.point.z < c.under_point.z);
+        Shape p = Shape::Plane();
+        i = ix(S2, p);
+        c = prepare_computation(i, ray(0, 1, -1, 0, -S2 / 2, S2 / 2), {i});
+        CHECK(veq(c.reflectv, 0, S2 / 2, S2 / 2));
+    });
+    run("intersection.n1_n2", [] {
+        Material ma = glass_material(), mb = glass_material(), mc = glass_material();
+        ma.index_of_refraction = 1.5, mb.index_of_refraction = 2.0, mc.index_of_refraction = 2.5;
+        Shape a = Shape::Sphere(ShapeBuilder{ma, Transform::scaling(2, 2, 2)});
+        Shape b = Shape::Sphere(ShapeBuilder{mb, Transform::translation(0, 0, -0.25)});
+        Shape c = Shape::Sphere(ShapeBuilder{mc, Transform::translation(0, 0, 0.25)});
+        std::vector<Intersection> xs{ix(2, a), ix(2.75, b), ix(3.25, c), ix(4.75, b), ix(5.25, c), ix(6, a)};
+        const double want[6][2] = {{1.0, 1.5}, {1.5, 2.0}, {2.0, 2.5}, {2.5, 2.5}, {2.5, 1.5}, {1.5, 1.0}};
+        for (int k = 0; k < 6; ++k) {
+            double n1, n2;
+            find_n1_and_n2(xs[k], xs, n1, n2);
+            CHECK_APPROX(n1, want[k][0]);
+            CHECK_APPROX(n2, want[k][1]);
+        }
+    });
+    run("intersection.schlick", [] {
+        Shape s = glass_sphere();
+        std::vector<Intersection> xs{ix(-S2 / 2, s), ix(S2 / 2, s)};
+        CHECK_APPROX(prepare_computation(xs[1], ray(0, 0, S2 / 2, 0, 1, 0), xs).schlick(), 1.0);
+        xs = {ix(-1, s), ix(1, s)};
+        CHECK_APPROX(prepare_computation(xs[1], ray(0, 0, 0, 0, 1, 0), xs).schlick(), 0.04);
+        xs = {ix(1.8589, s)};
+        CHECK_APPROX(prepare_computation(xs[0], ray(0, 0.99, -2, 0, 0, 1), xs).schlick(), 0.48873);
+    });
+
+    // ------------------------------------------------------------------ pattern.rs:162-460
+    run("pattern.stripe", [] {
+        Pattern3D p = Pattern3D::Stripe(Pattern3DSpec::make(color::WHITE, color::BLACK, Transform{}));
+        for (double y : {0.0, 1.0, 2.0}) CHECK(p.color_at(Point{0, y, 0}) == color::WHITE);
+        for (double z : {0.0, 1.0, 2.0}) CHECK(p.color_at(Point{0, 0, z}) == color::WHITE);
+        CHECK(p.color_at(Point{0.9, 0, 0}) == color::WHITE && p.color_at(Point{1.0, 0, 0}) == color::BLACK);
+        CHECK(p.color_at(Point{-0.1, 0, 0}) == color::BLACK && p.color_at(Point{-1.0, 0, 0}) == color::BLACK);
+        CHECK(p.color_at(Point{-1.1, 0, 0}) == color::WHITE);
+    });
+    run("pattern.transforms", [] {
+        World w;
+        Light l = Light::Point(PointLight{Point{0, 0, -10}, color::WHITE});
+        auto at = [&](const Transform& obj, const Transform& pat, Point p) {
+            Material m;
+            m.pattern = Pattern3D::Stripe(Pattern3DSpec::make(color::WHITE, color::BLACK, pat));
+            m.ambient = 1.0, m.diffuse = 0.0, m.specular = 0.0;
+            Shape s = Shape::Sphere(ShapeBuilder{m, obj});
+            return w.lighting(m, s, l, p, Vector{0, 0, -1}, Vector{0, 0, -1}, 0.0);
+        };
+        CHECK(at(Transform::scaling(2, 2, 2), Transform{}, Point{1.5, 0, 0}) == color::WHITE);
+        CHECK(at(Transform{}, Transform::scaling(2, 2, 2), Point{1.5, 0, 0}) == color::WHITE);
+        CHECK(at(Transform::scaling(2, 2, 2), Transform::translation(0.5, 0, 0), Point{2.5, 0, 0}) == color::WHITE);
+        // pattern.rs:255-320 (MockPattern returns the pattern-space point): check the point itself
+        Transform oi = Transform::scaling(2, 2, 2).inverse();
+        CHECK(peq(Transform{} * (oi * Point{2, 3, 4}), 1, 1.5, 2));
+        CHECK(peq(Transform::scaling(2, 2, 2).inverse() * (Transform{} * Point{2, 3, 4}), 1, 1.5, 2));
+        CHECK(peq(Transform::translation(0.5, 1, 1.5).inverse() * (oi * Point{2.5, 3, 3.5}), 0.75, 0.5, 0.25));
+    });
+    run("pattern.gradient_ring_checker", [] {
+        Pattern3D g = Pattern3D::Gradient(Pattern3DSpec::make(color::WHITE, color::BLACK, Transform{}));
+        CHECK(g.color_at(Point{0, 0, 0}) == color::WHITE);
+        CHECK(ceq(g.color_at(Point{0.25, 0, 0}), 0.75, 0.75, 0.75));
+        CHECK(ceq(g.color_at(Point{0.5, 0, 0}), 0.5, 0.5, 0.5));
+        CHECK(ceq(g.color_at(Point{0.75, 0, 0}), 0.25, 0.25, 0.25));
+        Pattern3D r = Pattern3D::Ring(Pattern3DSpec::make(color::WHITE, color::BLACK, Transform{}));
+        CHECK(r.color_at(Point{0, 0, 0}) == color::WHITE && r.color_at(Point{1, 0, 0}) == color::BLACK);
+        CHECK(r.color_at(Point{0, 0, 1}) == color::BLACK && r.color_at(Point{0.708, 0, 0.708}) == color::BLACK);
+        Pattern3D c = Pattern3D::Checker(Pattern3DSpec::make(color::WHITE, color::BLACK, Transform{}));
+        CHECK(c.color_at(Point{0, 0, 0}) == color::WHITE);
+        CHECK(c.color_at(Point{0.99, 0, 0}) == color::WHITE && c.color_at(Point{1.01, 0, 0}) == color::BLACK);
+        CHECK(c.color_at(Point{0, 0.99, 0}) == color::WHITE && c.color_at(Point{0, 1.01, 0}) == color::BLACK);
+        CHECK(c.color_at(Point{0, 0, 0.99}) == color::WHITE && c.color_at(Point{0, 0, 1.01}) == color::BLACK);
+    });
+
+    // ------------------------------------------------------------------ material.rs:199-503
+    run("material.lighting", [] {
+        World w;
+        Shape o = Shape::Sphere();
+        Material m;
+        Point p{0, 0, 0};
+        Vector n{0, 0, -1};
+        auto pl = [](double x, double y, double z) { return Light::Point(PointLight{Point{x, y, z}, color::WHITE}); };
+        CHECK(ceq(w.lighting(m, o, pl(0, 0, -10), p, Vector{0, 0, -1}, n, 1.0), 1.9, 1.9, 1.9));
+        CHECK(ceq(w.lighting(m, o, pl(0, 0, -10), p, Vector{0, S2 / 2, -S2 / 2}, n, 1.0), 1.0, 1.0, 1.0));
+        CHECK(ceq(w.lighting(m, o, pl(0, 10, -10), p, Vector{0, 0, -1}, n, 1.0), 0.7364, 0.7364, 0.7364));
+        CHECK(ceq(w.lighting(m, o, pl(0, 10, -10), p, Vector{0, -S2 / 2, -S2 / 2}, n, 1.0), 1.6364, 1.6364, 1.6364));
+        CHECK(ceq(w.lighting(m, o, pl(0, 0, 10), p, Vector{0, 0, -1}, n, 0.0), 0.1, 0.1, 0.1));
+        CHECK(ceq(w.lighting(m, o, pl(0, 0, 0), p, Vector{0, 0, -1}, n, 0.0), 0.1, 0.1, 0.1));
+        CHECK(ceq(w.lighting(m, o, pl(0, 0, -10), p, Vector{0, 0, -1}, n, 0.0), 0.1, 0.1, 0.1));
+        Material sm;
+        sm.pattern = Pattern3D::Stripe(Pattern3DSpec::make(color::WHITE, color::BLACK, Transform{}));
+        sm.ambient = 1.0, sm.diffuse = 0.0, sm.specular = 0.0;
+        CHECK(w.lighting(sm, o, pl(0, 0, -10), Point{0.9, 0, 0}, Vector{0, 0, -1}, n, 0.0) == color::WHITE);
+        CHECK(w.lighting(sm, o, pl(0, 0, -10), Point{1.1, 0, 0}, Vector{0, 0, -1}, n, 0.0) == color::BLACK);
+    });
+    run("material.intensity_attenuation_and_area", [] {
+        World w = test_world();
+        Material m = w.objects[0].cache.material;
+        m.ambient = 0.1, m.diffuse = 0.9, m.specular = 0.0, m.pattern = Pattern3D::Solid(color::WHITE);
+        Light l = Light::Point(PointLight{Point{0, 0, -10}, color::WHITE});
+        Point p{0, 0, -1};
+        Vector e{0, 0, -1}, n{0, 0, -1};
+        CHECK(w.lighting(m, w.objects[0], l, p, e, n, 1.0) == color::WHITE);
+        CHECK(ceq(w.lighting(m, w.objects[0], l, p, e, n, 0.5), 0.55, 0.55, 0.55));
+        CHECK(ceq(w.lighting(m, w.objects[0], l, p, e, n, 0.0), 0.1, 0.1, 0.1));
+        Light a = Light::Area(AreaLightBuilder{Point{-0.5, -0.5, -5}, Vector{1, 0, 0}, 2, Vector{0, 1, 0}, 2, color::WHITE});
+        Shape o = Shape::Sphere();
+        Material am;
+        am.ambient = 0.1, am.diffuse = 0.9, am.specular = 0.0;
+        Point eye{0, 0, -5};
+        Point p0{0, 0, -1};
+        CHECK(ceq(w.lighting(am, o, a, p0, (eye - p0).normalize(), Vector{p0.x, p0.y, p0.z}, 1.0), 0.9965, 0.9965, 0.9965));
+        Point p1{0, 0.7071, -0.7071};
+        CHECK(ceq(w.lighting(am, o, a, p1, (eye - p1).normalize(), Vector{p1.x, p1.y, p1.z}, 1.0), 0.62318, 0.62318, 0.62318));
+    });
+
+    // ------------------------------------------------------------------ light.rs:251-430
+    run("light.point_intensity", [] {
+        World w = test_world();
+        TraceCtx ctx;
+        const double pts[7][4] = {{0, 1.0001, 0, 1}, {-1.0001, 0, 0, 1}, {0, 0, -1.0001, 1}, {0, 0, 1.0001, 0},
+                                  {1.0001, 0, 0, 0}, {0, -1.0001, 0, 0}, {0, 0, 0, 0}};
+        for (const auto& p : pts) CHECK_APPROX(w.intensity_at(w.lights[0], 0, Point{p[0], p[1], p[2]}, ctx), p[3]);
+    });
+    run("light.area_construction_and_points", [] {
+        AreaLight a = AreaLight::from(AreaLightBuilder{Point{0, 0, 0}, Vector{2, 0, 0}, 4, Vector{0, 0, 1}, 2, color::WHITE});
+        CHECK(veq(a.uvec, 0.5, 0, 0) && a.usteps == 4 && veq(a.vvec, 0, 0, 0.5) && a.vsteps == 2 && a.samples == 8);
+        auto half = [] { return 0.5; };
+        CHECK(peq(a.point_on_light(0, 0, half), 0.25, 0, 0.25) && peq(a.point_on_light(1, 0, half), 0.75, 0, 0.25));
+        CHECK(peq(a.point_on_light(0, 1, half), 0.25, 0, 0.75) && peq(a.point_on_light(2, 0, half), 1.25, 0, 0.25));
+        CHECK(peq(a.point_on_light(3, 1, half), 1.75, 0, 0.75));
+        const double seq[2] = {0.3, 0.7};
+        size_t pos = 0;
+        auto mock = [&] { return seq[pos++ % 2]; };
+        CHECK(peq(a.point_on_light(0, 0, mock), 0.15, 0, 0.35) && peq(a.point_on_light(1, 0, mock), 0.65, 0, 0.35));
+        CHECK(peq(a.point_on_light(0, 1, mock), 0.15, 0, 0.85) && peq(a.point_on_light(2, 0, mock), 1.15, 0, 0.35));
+        CHECK(peq(a.point_on_light(3, 1, mock), 1.65, 0, 0.85));
+    });
+    run("light.area_intensity", [] {
+        World w = test_world();
+        Light a = Light::Area(AreaLightBuilder{Point{-0.5, -0.5, -5}, Vector{1, 0, 0}, 2, Vector{0, 1, 0}, 2, color::WHITE});
+        TraceCtx ctx;  // CENTER == MockJitter([0.5])
+        const double pts[5][4] = {{0, 0, 2, 0.0}, {1, -1, 2, 0.25}, {1.5, 0, 2, 0.5}, {1.25, 1.25, 3, 0.75}, {0, 0, -2, 1.0}};
+        for (const auto& p : pts) CHECK_APPROX(w.intensity_at(a, 0, Point{p[0], p[1], p[2]}, ctx), p[3]);
+        // SEQUENCE mode reproduces a cyclic MockJitter
+        std::vector<double> seq{0.5};
+        size_t pos = 0;
+        TraceCtx sctx;
+        sctx.mode = JitterMode::SEQUENCE, sctx.sequence = &seq, sctx.seq_pos = &pos;
+        CHECK_APPROX(w.intensity_at(a, 0, Point{1.25, 1.25, 3}, sctx), 0.75);
+        CHECK(pos == 8);
+    });
+
+    // ------------------------------------------------------------------ world.rs:201-858
+    run("world.intersect", [] {
+        World w = test_world();
+        auto xs = w.intersect(ray(0, 0, -5, 0, 0, 1));
+        CHECK(xs.size() == 4);
+        if (xs.size() == 4) {
+            CHECK_APPROX(xs[0].t, 4.0);
+            CHECK_APPROX(xs[1].t, 4.5);
+            CHECK_APPROX(xs[2].t, 5.5);
+            CHECK_APPROX(xs[3].t, 6.0);
+        }
+    });
+    run("world.shade_hit", [] {
+        World w = test_world();
+        Ray r = ray(0, 0, -5, 0, 0, 1);
+        Intersection i = ix(4, w.objects[0]);
+        CHECK(ceq(w.shade_hit(prepare_computation(i, r, {i}), RECURSION_DEPTH, TraceCtx{}), 0.38066, 0.47583, 0.2855));
+        World w2 = test_world();
+        w2.lights = {Light::Point(PointLight{Point{0, 0.25, 0}, color::WHITE})};
+        r = ray(0, 0, 0, 0, 0, 1);
+        i = ix(0.5, w2.objects[1]);
+        CHECK(ceq(w2.shade_hit(prepare_computation(i, r, {i}), RECURSION_DEPTH, TraceCtx{}), 0.90498, 0.90498, 0.90498));
+        World w3 = test_world();
+        w3.lights.clear();
+        i = ix(0.5, w3.objects[1]);
+        CHECK(w3.shade_hit(prepare_computation(i, r, {i}), RECURSION_DEPTH, TraceCtx{}) == color::BLACK);
+    });
+    run("world.color_at", [] {
+        World w = test_world();
+        CHECK(w.color_at(ray(0, 0, -5, 0, 1, 0), RECURSION_DEPTH) == color::BLACK);
+        CHECK(ceq(w.color_at(ray(0, 0, -5, 0, 0, 1), RECURSION_DEPTH), 0.38066, 0.47583, 0.2855));
+        w.objects[0].cache.material.ambient = 1.0;
+        w.objects[1].cache.material.ambient = 1.0;
+        Color c = w.color_at(ray(0, 0, 0.75, 0, 0, -1), RECURSION_DEPTH);
+        CHECK(c == w.objects[1].cache.material.pattern.solid);
+    });
+    run("world.is_shadowed", [] {
+        World w = test_world();
+        TraceCtx ctx;
+        Point lp{-10, 10, -10};
+        CHECK(!w.is_shadowed(lp, Point{0, 10, 0}, ctx));
+        CHECK(w.is_shadowed(lp, Point{10, -10, 10}, ctx));
+        CHECK(!w.is_shadowed(lp, Point{-20, 20, -20}, ctx));
+        CHECK(!w.is_shadowed(lp, Point{-2, 2, -2}, ctx));
+        World e;
+        CHECK(!e.is_shadowed(lp, Point{1, 2, 3}, ctx));
+        Point l2{-10, -10, -10};  // world.rs:851-858
+        CHECK(!w.is_shadowed(l2, Point{-10, -10, 10}, ctx));
+        CHECK(w.is_shadowed(l2, Point{10, 10, 10}, ctx));
+        CHECK(!w.is_shadowed(l2, Point{-20, -20, -20}, ctx));
+        CHECK(!w.is_shadowed(l2, Point{-5, -5, -5}, ctx));
+    });
+    run("world.shade_hit_in_shadow", [] {
+        World w;
+        w.objects.push_back(Shape::Sphere());
+        w.objects.push_back(Shape::Sphere(ShapeBuilder{Material{}, Transform::translation(0, 0, 10)}));
+        w.lights.push_back(Light::Point(PointLight{Point{0, 0, -10}, color::WHITE}));
+        Intersection i = ix(4, w.objects[1]);
+        CHECK(ceq(w.shade_hit(prepare_computation(i, ray(0, 0, 5, 0, 0, 1), {i}), RECURSION_DEPTH, TraceCtx{}), 0.1, 0.1, 0.1));
+    });
+    run("world.reflection", [] {
+        World w = test_world();
+        w.objects[1].cache.material.ambient = 1.0;
+        Intersection i = ix(1, w.objects[1]);
+        CHECK(w.reflected_color(prepare_computation(i, ray(0, 0, 0, 0, 0, 1), {i}), RECURSION_DEPTH, TraceCtx{}) == color::BLACK);
+        World w2 = test_world();
+        Material pm;
+        pm.reflectivity = 0.5;
+        Shape plane = Shape::Plane(ShapeBuilder{pm, Transform::translation(0, -1, 0)});
+        Ray r = ray(0, 0, -3, 0, -S2 / 2, S2 / 2);
+        i = ix(S2, plane);
+        Computation comps = prepare_computation(i, r, {i});
+        CHECK(ceq(w2.reflected_color(comps, RECURSION_DEPTH, TraceCtx{}), 0.19033, 0.23791, 0.14275));
+        CHECK(ceq(w2.shade_hit(comps, RECURSION_DEPTH, TraceCtx{}), 0.87676, 0.92435, 0.82918));
+        CHECK(w2.reflected_color(comps, 0, TraceCtx{}) == color::BLACK);  // world.rs:609-638
+    });
+    run("world.mutually_reflective_terminates", [] {
+        Material m;
+        m.reflectivity = 1.0;
+        World w;
+        w.objects.push_back(Shape::Sphere(ShapeBuilder{m, Transform::translation(0, -1, 0)}));
+        w.objects.push_back(Shape::Sphere(ShapeBuilder{m, Transform::translation(0, 1, 0)}));
+        w.lights.push_back(Light::Point(PointLight{Point{0, 0, 0}, color::WHITE}));
+        Color c = w.color_at(ray(0, 0, 0, 0, 1, 0), RECURSION_DEPTH);
+        CHECK(c.red == c.red);
+    });
+    run("world.refraction", [] {
+        World w = test_world();
+        Ray r = ray(0, 0, -5, 0, 0, 1);
+        std::vector<Intersection> xs{ix(4, w.objects[0]), ix(6, w.objects[0])};
+        CHECK(w.refracted_color(prepare_computation(xs[0], r, xs), RECURSION_DEPTH, TraceCtx{}) == color::BLACK);
+        w.objects[0].cache.material.index_of_refraction = 1.5;
+        w.objects[0].cache.material.transparency = 1.0;
+        CHECK(w.refracted_color(prepare_computation(xs[0], r, xs), 0, TraceCtx{}) == color::BLACK);
+        Ray r2 = ray(0, 0, S2 / 2, 0, 1, 0);
+        std::vector<Intersection> ys{ix(-S2 / 2, w.objects[0]), ix(S2 / 2, w.objects[0])};
+        CHECK(w.refracted_color(prepare_computation(ys[1], r2, ys), RECURSION_DEPTH, TraceCtx{}) == color::BLACK);
+    });
+    run("world.transparent_floor", [] {
+        auto build = [](double reflectivity) {
+            World w = test_world();
+            Material fm;
+            fm.index_of_refraction = 1.5, fm.transparency = 0.5, fm.reflectivity = reflectivity;
+            w.objects.push_back(Shape::Plane(ShapeBuilder{fm, Transform::translation(0, -1, 0)}));
+            Material bm;
+            bm.ambient = 0.5, bm.pattern = Pattern3D::Solid(color::RED);
+            w.objects.push_back(Shape::Sphere(ShapeBuilder{bm, Transform::translation(0, -3.5, -0.5)}));
+            return w;
+        };
+        Ray r = ray(0, 0, -3, 0, -S2 / 2, S2 / 2);
+        World w = build(0.0);
+        std::vector<Intersection> xs{ix(S2, w.objects[2])};
+        CHECK(ceq(w.shade_hit(prepare_computation(xs[0], r, xs), RECURSION_DEPTH, TraceCtx{}), 0.93642, 0.68642, 0.68642));
+        World w2 = build(0.5);
+        xs = {ix(S2, w2.objects[2])};
+        CHECK(ceq(w2.shade_hit(prepare_computation(xs[0], r, xs), RECURSION_DEPTH, TraceCtx{}), 0.93391, 0.69643, 0.69243));
+    });
+
+    std::printf("SUMMARY cases=%d failed=%d\n", g_cases, g_fail);
+    return g_fail ? 1 : 0;
+}
