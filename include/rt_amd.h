@@ -1,0 +1,179 @@
+/* rt_amd.h — C ABI of librt_amd.so: the MI355X (gfx950) replacement for the per-pixel render
+ * path of regexPattern/raytracer.
+ *
+ * What it replaces (reference file:line, relative to the reference repo root):
+ *   Camera::render            src/camera.rs:163-208   -> rt_render / rt_render_device
+ *   Canvas::to_image          src/canvas.rs:31-45     -> rt_quantize_u8 / rt_quantize_u8_device
+ * and everything those call per pixel: Camera::ray_for_pixel (camera.rs:210-228),
+ * World::{color_at,intersect,shade_hit,is_shadowed,reflected_color,refracted_color}
+ * (world.rs:24-133), Shape::{intersect,normal_at} + every file under shape/, Intersection::{prepare_computation,
+ * find_n1_and_n2,sort,hit} and Computation::schlick (intersection.rs:40-141), Light::intensity_at /
+ * AreaLight::intensity_at (light.rs:147-216), Material::lighting (material.rs:118-162),
+ * Pattern3D::color_at_object (pattern.rs:58-96).
+ *
+ * The caller (the reference's Rust side, or the C++ mirror in include/raytracer_amd/) keeps
+ * building World / Camera exactly as in the reference's examples and compiles them ONCE into the flat
+ * structure-of-arrays description below (values computed in f64, rounded once to f32).  Every
+ * pointer is plain host memory owned by the caller and only read during the call that takes it.
+ * No C++ or torch types cross this boundary; no function throws or aborts; every function returns
+ * RT_OK (0) or a negative rt_status and leaves a message for rt_last_error().
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_BAD_ARGUMENT = -1,   /* null pointer, zero size, index out of range, malformed tree */
+    RT_ERR_UNSUPPORTED = -2,    /* unknown primitive / pattern / light tag                     */
+    RT_ERR_CAPACITY = -3,       /* a stated limit exceeded (RT_MAX_*)                          */
+    RT_ERR_HIP = -4,            /* a HIP runtime call failed (message holds hipGetErrorString) */
+    RT_ERR_NO_DEVICE = -5       /* no usable gfx950 device                                     */
+} rt_status;
+
+/* Shape enum, shape.rs:33-41 (Group is not a primitive: it becomes rt node records). */
+enum { RT_PRIM_SPHERE = 0, RT_PRIM_PLANE = 1, RT_PRIM_CUBE = 2, RT_PRIM_CYLINDER = 3,
+       RT_PRIM_TRIANGLE = 4, RT_PRIM_SMOOTH_TRIANGLE = 5 };
+/* Pattern3D enum, pattern.rs:16-31 */
+enum { RT_PAT_SOLID = 0, RT_PAT_STRIPE = 1, RT_PAT_GRADIENT = 2, RT_PAT_RING = 3, RT_PAT_CHECKER = 4 };
+/* Light enum, light.rs:14-20 */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+/* light.rs:149-152 draws thread_rng u8 / 255; here: 0 = every draw is 0.5 (deterministic parity
+ * mode), 1 = counter-based hash of (seed, pixel, path node, light, cell, axis) -> top 8 bits / 255 */
+enum { RT_JITTER_CENTER = 0, RT_JITTER_COUNTER = 1 };
+
+#define RT_MAX_DEPTH 8u            /* options.max_depth limit (reference: RECURSION_DEPTH = 5)  */
+#define RT_MAX_LIGHTS 256u
+#define RT_MAX_LIGHT_CELLS 32768u  /* usteps * vsteps per area light                            */
+#define RT_ITEM_NODE 0x80000000u   /* item_ref bit: the item is a node, not a primitive         */
+
+/* Flat scene.  Transforms are affine (bottom row 0,0,0,1 — every public constructor of
+ * transform.rs:141-275 and their products/inverses), stored as the first three rows, row-major,
+ * 12 floats.  "inv" always means the object's (or pattern's) transform_inverse.
+ *
+ * Traversal items: the reference tests world.objects in order and, for a Group, its children in
+ * order after a box test (world.rs:32-41, group.rs:106-119).  The same order is given here as ONE
+ * array of items in depth-first pre-order.  Item i is either primitive item_ref[i], or node
+ * (item_ref[i] & ~RT_ITEM_NODE) whose subtree is items (i, item_next[i]); item_next[i] is the
+ * item visited when the subtree is skipped (i + 1 for a primitive).  A node's box is the merge of
+ * its children's parent_space_bounding_box — what Group::bounding_box() (group.rs:233-242)
+ * recomputes for every ray. */
+typedef struct rt_scene_desc {
+    uint32_t abi_version;          /* RT_ABI_VERSION */
+
+    uint32_t n_prims;
+    const uint8_t* prim_type;      /* [n_prims]      RT_PRIM_*                                      */
+    const float* prim_inv;         /* [n_prims][12]  transform_inverse, object.rs:9                  */
+    const uint32_t* prim_material; /* [n_prims]      index into mat_*                                */
+    const float* prim_param;       /* [n_prims][24]  cylinder: min, max, closed(0/1)  (cylinder.rs:42-47)
+                                                     triangle: v0[3], e0[3], e1[3], normal[3]       (triangle.rs:48-56)
+                                                     smooth:   + n0[3], n1[3], n2[3]                (smooth_triangle.rs:14-19)
+                                                     others: ignored.  May be NULL if no primitive needs it. */
+
+    uint32_t n_nodes;
+    const float* node_min;         /* [n_nodes][3]   may hold +-inf                                   */
+    const float* node_max;         /* [n_nodes][3]                                                   */
+
+    uint32_t n_items;
+    const uint32_t* item_ref;      /* [n_items]                                                      */
+    const uint32_t* item_next;     /* [n_items]      i < item_next[i] <= n_items                     */
+
+    uint32_t n_materials;
+    const float* mat_param;        /* [n_materials][8] ambient, diffuse, specular, shininess,
+                                                       index_of_refraction, reflectivity, transparency, 0
+                                                       (material.rs:37-87)                           */
+    const uint32_t* mat_pattern;   /* [n_materials]  index into pat_*                                */
+
+    uint32_t n_patterns;
+    const uint8_t* pat_type;       /* [n_patterns]   RT_PAT_*                                        */
+    const float* pat_color_a;      /* [n_patterns][3] (Solid: the colour)                            */
+    const float* pat_color_b;      /* [n_patterns][3]                                                */
+    const float* pat_inv;          /* [n_patterns][12] pattern transform_inverse (identity for Solid) */
+
+    uint32_t n_lights;             /* world.lights order (world.rs:44)                               */
+    const uint8_t* light_type;     /* [n_lights]     RT_LIGHT_*                                      */
+    const float* light_pos;        /* [n_lights][3]  point: position; area: corner  (light.rs:42-48,81-89) */
+    const float* light_uvec;       /* [n_lights][3]  area: horizontal_dir / usteps                   */
+    const float* light_vvec;       /* [n_lights][3]  area: vertical_dir / vsteps                     */
+    const uint32_t* light_usteps;  /* [n_lights]     1 for point lights                              */
+    const uint32_t* light_vsteps;  /* [n_lights]                                                     */
+    const float* light_color;      /* [n_lights][3]  intensity                                       */
+} rt_scene_desc;
+
+/* Camera, camera.rs:64-73 after Camera::try_from (camera.rs:95-136). */
+typedef struct rt_camera_desc {
+    uint32_t hsize, vsize;
+    float pixel_size, half_width, half_height;
+    float inv[12];                 /* transform_inverse, first three rows                            */
+} rt_camera_desc;
+
+/* Row tiles for multi-GPU partitioning: the image is cut into bands of `tile_rows` pixel rows;
+ * this call renders bands tile_first, tile_first + tile_stride, ... and packs them one after
+ * another into the output (band k of this call starts at output row k * tile_rows).  The defaults
+ * (tile_rows = 0) render the whole image.  The jitter hash is keyed on the GLOBAL pixel index, so
+ * the image does not depend on the partition. */
+typedef struct rt_options {
+    uint32_t max_depth;            /* world.rs:11 RECURSION_DEPTH; 0 in a zeroed struct means 5      */
+    uint32_t jitter_mode;          /* RT_JITTER_*                                                    */
+    uint32_t seed;
+    uint32_t tile_rows, tile_first, tile_stride;
+    uint32_t flags;                /* reserved, must be 0                                            */
+} rt_options;
+
+/* Ray and work counters of one render (unique rays actually traced; the reference-equivalent
+ * count, which re-traces the recursion once per light, is derived by the caller). */
+typedef struct rt_stats {
+    uint64_t primary_rays, reflection_rays, refraction_rays, shadow_rays;
+    uint64_t shaded_hits, light_cells, pattern_lookups, container_passes;
+    uint64_t pixels;
+    float kernel_ms;               /* hipEvent time of the render kernel(s) on the scene's stream    */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque: device-resident copy of a scene on ONE GPU */
+
+/* Library / device. */
+uint32_t rt_abi_version(void);
+const char* rt_last_error(void);                      /* thread-local message of the last failure   */
+int rt_device_count(int* count_out);
+
+/* Copies the description to `device` (HIP ordinal) and prepares it for rendering.  Validates every
+ * index and the item tree (so that traversal always terminates).  Replaces building/borrowing
+ * `&World` in Camera::render(&self, world: &World), camera.rs:163. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Number of output rows a call with these options produces (<= camera vsize). */
+int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint32_t* rows_out);
+
+/* Camera::render, camera.rs:163-208.  rgb_out: rows * hsize * 3 floats, row-major, row 0 = top,
+ * red/green/blue per pixel — the Canvas contents in canvas.rs:8-12 order.
+ *   rt_render_device: rgb_out is DEVICE memory on the scene's GPU; the work is enqueued on
+ *                     `stream` (a hipStream_t passed as void*, NULL = the default stream) and the
+ *                     call returns without waiting.  Allocates nothing.
+ *   rt_render:        rgb_out is HOST memory; the call allocates a device image, renders, copies
+ *                     back and waits.  stats_out may be NULL. */
+int rt_render_device(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
+                     float* rgb_out_device, void* stream);
+int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host,
+              rt_stats* stats_out);
+/* Same image, plus the counters (uses the instrumented kernel variant; slower). rgb may be NULL. */
+int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
+                    float* rgb_out_host, rt_stats* stats_out);
+
+/* Canvas::to_image, canvas.rs:31-45: out[i] = (rgb[i] * 255.0) as u8 — truncate toward zero,
+ * saturate to 0..255, NaN -> 0.  n = number of floats. */
+int rt_quantize_u8_device(const float* rgb_device, size_t n, uint8_t* out_device, int device, void* stream);
+int rt_quantize_u8(const float* rgb_host, size_t n, uint8_t* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -86,11 +86,13 @@ int oracle_probe_pixels(const char* name, int width, int height, int jitter_mode
         TraceCtx ctx;
         ctx.mode = opt.jitter;
         ctx.rng = &rng;
+        tls_debug = std::getenv("ORACLE_DEBUG") != nullptr;
         for (int i = 0; i < n; ++i) {
             Color c = scene.camera.color_for_pixel(scene.world, static_cast<size_t>(xy[2 * i]),
                                                    static_cast<size_t>(xy[2 * i + 1]), opt, ctx);
             rgb[3 * i] = c.red, rgb[3 * i + 1] = c.green, rgb[3 * i + 2] = c.blue;
         }
+        tls_debug = false;
         return 0;
     } catch (const std::exception& e) {
         return fail(e.what());

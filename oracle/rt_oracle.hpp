@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <mutex>
@@ -106,6 +107,7 @@ struct RayStats {  // one "ray" = one World::intersect call in reference semanti
 };
 // Per-thread sink for primitive-test counts (set by Camera::render workers; null = off).
 inline thread_local RayStats* tls_stats = nullptr;
+inline thread_local bool tls_debug = false;  // oracle_probe_pixels(debug): print every shaded path node
 
 // ---------------------------------------------------------------------------------------------
 // tuple.rs:74-236 — Point (w = 1) and Vector (w = 0).  The w lane is carried implicitly: every
@@ -1226,6 +1228,12 @@ struct World {
                 reflectance = reflected + refracted;
             }
             acc = acc + surface + reflectance;
+            if (tls_debug)
+                std::printf("  [oracle] node=%u depth=%u light=%u t=%.9g kind=%d p=(%.9g %.9g %.9g) n=(%.9g %.9g %.9g) inside=%d n1=%.6g n2=%.6g I=%.6g surf=(%.9g %.9g %.9g) refl=(%.9g %.9g %.9g) refr=(%.9g %.9g %.9g)\n",
+                            ctx.node, unsigned(depth), li, comps.intersection.t, int(object.kind), comps.point.x, comps.point.y, comps.point.z,
+                            comps.normalv.x, comps.normalv.y, comps.normalv.z, int(comps.inside), comps.n1, comps.n2, light_intensity,
+                            surface.red, surface.green, surface.blue, reflected.red, reflected.green, reflected.blue,
+                            refracted.red, refracted.green, refracted.blue);
             ++li;
         }
         return acc;

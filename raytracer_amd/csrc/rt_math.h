@@ -1,0 +1,580 @@
+// rt_math.h — per-lane FP32 arithmetic of the gfx950 render kernels: ray/primitive intersection,
+// hit preparation, patterns, Phong terms, Schlick/refraction, the jitter hash.
+//
+// Every function is `RT_HD` (host + device) so that the SAME arithmetic can be compiled by g++
+// into tests/cpp/hostsim.cpp (a test-only executable spec used to debug f32-vs-f64 parity in a
+// container without a GPU).  The product library only ever runs these on the GPU.
+//
+// Numerical design (DESIGN.md §"FP32 against an f64 reference with EPSILON = 1e-5"):
+//  * the reference offsets secondary-ray origins by normal * 1e-5 (intersection.rs:52-53), which
+//    is below FP32 resolution for |coordinate| >~ 100 and comparable to FP32 error at ~10.  A ray
+//    that starts on primitive P therefore carries P's id, the hit point SNAPPED onto P's surface
+//    in P's object space (`q`) and the object-space offset (`dq`); the intersection with P itself
+//    is computed from (q, dq) analytically, so the sign of the near-zero root — the thing that
+//    decides self-shadowing — is exact, and patterns are evaluated at q + dq;
+//  * the sphere discriminant uses the perpendicular-distance form, not b^2 - 4ac (sphere.rs:49),
+//    which cancels catastrophically in FP32 for far ray origins.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtk {
+
+constexpr float kEps = 1e-5f;  // float.rs:3
+
+// Device-side records (built by rt_scene_create from rt_scene_desc; see DESIGN.md "HBM layout").
+struct DPrim {  // 64 B — one s_load_dwordx16 when the index is wave-uniform
+    float inv[12];
+    uint32_t type;
+    uint32_t material;
+    float ior;  // copy of the material's index_of_refraction (container pass)
+    uint32_t extra;
+};
+struct DExtra {  // 128 B: cylinder {min,max,closed}; triangle {v0,e0,e1,normal,n0,n1,n2}
+    float f[32];
+};
+struct DItem {
+    uint32_t ref, next;
+};
+struct DNode {  // 32 B
+    float mn[3], pad0, mx[3], pad1;
+};
+struct DMaterial {  // 32 B
+    float ambient, diffuse, specular, shininess, ior, reflectivity, transparency;
+    uint32_t pattern;
+};
+struct DPattern {  // 80 B
+    float inv[12];
+    float a[3];
+    uint32_t type;
+    float b[3];
+    float pad;
+};
+struct DLight {  // 64 B
+    float pos[3];
+    uint32_t type;
+    float uvec[3];
+    uint32_t usteps;
+    float vvec[3];
+    uint32_t vsteps;
+    float color[3];
+    float inv_samples;
+};
+struct DCamera {
+    float pixel_size, half_width, half_height;
+    uint32_t hsize, vsize;
+    float inv[12];
+};
+
+enum : uint32_t { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_CUBE = 2, PRIM_CYLINDER = 3, PRIM_TRIANGLE = 4, PRIM_SMOOTH = 5 };
+enum : uint32_t { PAT_SOLID = 0, PAT_STRIPE = 1, PAT_GRADIENT = 2, PAT_RING = 3, PAT_CHECKER = 4 };
+constexpr uint32_t kItemNode = 0x80000000u;
+constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+
+struct V3 {
+    float x, y, z;
+};
+RT_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RT_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_HD V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RT_HD float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RT_HD V3 cross(V3 a, V3 b) {
+    return V3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
+// a*b - c*d with one rounding's worth of error (Kahan): used where nearly parallel vectors cancel.
+RT_HD float diff_of_products(float a, float b, float c, float d) {
+    float w = c * d;
+    float e = fmaf(c, d, -w);  // exact rounding error of w
+    float f = fmaf(a, b, -w);
+    return f - e;
+}
+RT_HD V3 cross_exact(V3 a, V3 b) {
+    return V3{diff_of_products(a.y, b.z, a.z, b.y), diff_of_products(a.z, b.x, a.x, b.z), diff_of_products(a.x, b.y, a.y, b.x)};
+}
+RT_HD V3 madd(V3 d, float t, V3 o) { return V3{fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }  // o + d*t
+RT_HD V3 normalize(V3 a) {
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return a * inv;
+}
+
+// 3x4 affine (rows) applied to a point / a vector / transposed-linear applied to a normal.
+RT_HD V3 xform_point(const float* m, V3 p) {
+    return V3{fmaf(m[0], p.x, fmaf(m[1], p.y, fmaf(m[2], p.z, m[3]))), fmaf(m[4], p.x, fmaf(m[5], p.y, fmaf(m[6], p.z, m[7]))),
+              fmaf(m[8], p.x, fmaf(m[9], p.y, fmaf(m[10], p.z, m[11])))};
+}
+RT_HD V3 xform_vector(const float* m, V3 v) {
+    return V3{fmaf(m[0], v.x, fmaf(m[1], v.y, m[2] * v.z)), fmaf(m[4], v.x, fmaf(m[5], v.y, m[6] * v.z)),
+              fmaf(m[8], v.x, fmaf(m[9], v.y, m[10] * v.z))};
+}
+RT_HD V3 xform_normal(const float* m, V3 n) {  // transform_inverse.transpose() * n, w dropped (shape.rs:89-90)
+    return V3{fmaf(m[0], n.x, fmaf(m[4], n.y, m[8] * n.z)), fmaf(m[1], n.x, fmaf(m[5], n.y, m[9] * n.z)),
+              fmaf(m[2], n.x, fmaf(m[6], n.y, m[10] * n.z))};
+}
+
+// float.rs:5-37 in f32
+RT_HD bool approx(float a, float b) {
+    if (isinf(a) && isinf(b)) return a == b;
+    return fabsf(a - b) <= kEps;
+}
+// partial_cmp(a,b) == Greater  (NaN => Greater, float.rs:29-37)
+RT_HD bool cmp_greater(float a, float b) { return !approx(a, b) && !(a < b); }
+// cube.rs:63-73: max_by keeps the last of approx-equal maxima, min_by the first of approx-equal minima
+RT_HD float max_by3(float a, float b, float c) {
+    float m = cmp_greater(a, b) ? a : b;
+    return cmp_greater(m, c) ? m : c;
+}
+RT_HD float min_by3(float a, float b, float c) {
+    float m = cmp_greater(a, b) ? b : a;
+    return cmp_greater(m, c) ? c : m;
+}
+
+// Nearest-hit selection with the reference's tie rule.  Intersection::sort (intersection.rs:105-115)
+// calls two t "Equal" when |dt| <= 1e-5 and the (insertion) sort keeps equal elements in the order
+// they were produced, i.e. world.objects order; Intersection::hit then takes the first t > 0.0.
+// Primitives are visited in that same order here, so a later candidate replaces the current best
+// only if it is smaller AND not approximately equal (e.g. the edge where two walls meet).
+//
+// FP32 cannot resolve |dt| below ~1e-6 * t, so a tie that is EXACT in the reference (a ray hitting
+// the edge where two planes meet — every example scene has such edges, and cameras on their
+// symmetry planes) would be decided by rounding noise once t > ~10.  The tie window is therefore
+// 1e-5 * max(1, t/4): the reference's own window wherever FP32 can resolve it, wider only where it
+// cannot.
+RT_HD float tie_window(float t) { return kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
+RT_HD bool closer_hit(float t, float best) { return t > 0.0f && t < best - tie_window(t); }  // best may be +inf
+// Does an intersection of primitive `prim` come before the hit (hit_prim, t_hit) in that sorted list?
+RT_HD bool precedes_hit(float t, float t_hit, uint32_t prim, uint32_t hit_prim) {
+    return (fabsf(t - t_hit) <= tie_window(t_hit)) ? (prim < hit_prim) : (t < t_hit);
+}
+
+// A ray in world space plus what it knows about the primitive it starts on.
+struct Ray {
+    V3 o, d;
+    uint32_t self;  // primitive the origin sits on, or kNoPrim
+    V3 q;           // snapped object-space point on `self`
+    V3 dq;          // object-space offset: origin_obj = q + dq  (= +-1e-5 * inv_linear * world normal)
+};
+
+// Up to four parametric hits of one primitive (cylinder: 2 wall + 2 caps), plus triangle (u, v).
+// `n` is the number of slots to look at and depends only on the primitive TYPE (so it is
+// wave-uniform); an absent intersection is NaN, which fails every ordered comparison the visitors
+// make (t > 0, t < best, t < t_hit).  Slots are only ever indexed by constants: they stay in VGPRs.
+struct Hits {
+    int n;
+    float t[4];
+    float u, v;
+};
+#define RT_NOHIT __builtin_nanf("")
+
+// ---------------------------------------------------------------------------------------------
+// Foot of the perpendicular from the unit sphere's centre onto the line o + t d, in FP32 without
+// the cancellation of b^2 - 4ac: tc = -(d.o)/a is refined by one Gram-Schmidt step (the residual
+// l.d is tiny and therefore known to full relative accuracy), after which l is perpendicular to d
+// to ~1e-7 and the roots are tc -+ half with half = sqrt((1 - |l|^2)/a).  The hit POINT is then
+// l -+ half*d (prepare_hit), whose error is ~1e-7 object units however far away the ray started;
+// o + t*d would carry the full rounding error of t (~1e-7 * distance) into the normal.
+RT_HD bool sphere_foot(V3 o, V3 d, float a, float& tc, V3& l, float& half) {
+    float inv_a = 1.0f / a;
+    float tc0 = -dot(d, o) * inv_a;
+    V3 l0 = madd(d, tc0, o);
+    float e = dot(l0, d) * inv_a;
+    tc = tc0 - e;
+    l = madd(d, -e, l0);
+    float m = 1.0f - dot(l, l);
+    half = sqrtf(fmaxf(m, 0.0f) * inv_a);
+    return !(m < 0.0f);
+}
+
+// sphere.rs:38-72.  a = d.d, h = d.o (= b/2), c = o.o - 1.  Always two roots when it hits.
+RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Hits& r) {
+    r.n = 2;
+    r.t[0] = RT_NOHIT, r.t[1] = RT_NOHIT;
+    float a = dot(d, d);
+    if (self) {
+        // |q| == 1 exactly by construction, so c = |q + dq|^2 - 1 = 2 q.dq + dq.dq without cancellation
+        V3 os = q + dq;
+        float h = dot(d, os);
+        float c = fmaf(2.0f, dot(q, dq), dot(dq, dq));
+        float disc = fmaf(h, h, -(a * c));
+        if (disc < 0.0f) return;
+        float sq = sqrtf(disc);
+        float qq = -(h + copysignf(sq, h));
+        float ta = qq / a;
+        float tb = (qq != 0.0f) ? c / qq : ta;
+        r.t[0] = fminf(ta, tb);
+        r.t[1] = fmaxf(ta, tb);
+        return;
+    }
+    float tc, half;
+    V3 l;
+    if (!sphere_foot(o, d, a, tc, l, half)) return;  // discriminant < 0  (sphere.rs:51)
+    r.t[0] = tc - half;
+    r.t[1] = tc + half;
+}
+
+// plane.rs:39-51 — only the y row of the inverse is needed.
+RT_HD void isect_plane(float oy, float dy, Hits& r) {
+    r.n = 1;
+    r.t[0] = (fabsf(dy) <= kEps) ? RT_NOHIT : -oy / dy;
+}
+
+// cube.rs:39-122 (the same slab code serves Group boxes: bounding_box.rs:81-84).
+// num_lo / num_hi are (min - origin) and (max - origin) per axis.
+RT_HD void slab_axis(float num_lo, float num_hi, float d, float& tmin, float& tmax) {
+    // cube.rs:83: `ge(|d|, EPSILON)` is approximate and therefore true for every finite d, so the
+    // IEEE division below (x/0 = +-inf, 0/0 = NaN) is what the reference always executes.
+    float a = num_lo / d, b = num_hi / d;
+    bool sw = a > b;
+    tmin = sw ? b : a;
+    tmax = sw ? a : b;
+}
+RT_HD void isect_box(V3 num_lo, V3 num_hi, V3 d, float& tmin, float& tmax) {
+    float x0, x1, y0, y1, z0, z1;
+    slab_axis(num_lo.x, num_hi.x, d.x, x0, x1);
+    slab_axis(num_lo.y, num_hi.y, d.y, y0, y1);
+    slab_axis(num_lo.z, num_hi.z, d.z, z0, z1);
+    tmin = max_by3(x0, y0, z0);
+    tmax = min_by3(x1, y1, z1);
+}
+RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Hits& r) {
+    V3 lo, hi;
+    if (self) {  // the snapped coordinate of q is exactly +-1, so (bound - q) is exactly 0 or +-2
+        lo = (v3(-1.0f, -1.0f, -1.0f) - q) - dq;
+        hi = (v3(1.0f, 1.0f, 1.0f) - q) - dq;
+    } else {
+        lo = v3(-1.0f, -1.0f, -1.0f) - o;
+        hi = v3(1.0f, 1.0f, 1.0f) - o;
+    }
+    float tmin, tmax;
+    isect_box(lo, hi, d, tmin, tmax);
+    const bool miss = tmin > tmax;  // cube.rs:104
+    r.n = 2;
+    r.t[0] = miss ? RT_NOHIT : tmin;
+    r.t[1] = miss ? RT_NOHIT : tmax;
+}
+
+// cylinder.rs:126-225
+RT_HD bool cyl_check_cap(float ox, float oz, float dx, float dz, float t) {
+    float x = fmaf(t, dx, ox), z = fmaf(t, dz, oz);
+    float rr = fmaf(x, x, z * z);
+    return approx(rr, 1.0f) || rr < 1.0f;  // le(x^2 + z^2, 1)
+}
+RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float ymax, bool closed, Hits& r) {
+    r.n = 4;
+    r.t[0] = RT_NOHIT, r.t[1] = RT_NOHIT, r.t[2] = RT_NOHIT, r.t[3] = RT_NOHIT;
+    V3 os = self ? q + dq : o;
+    float a = fmaf(d.x, d.x, d.z * d.z);
+    if (!approx(a, 0.0f)) {
+        float t0, t1;
+        if (self && fabsf(fmaf(q.x, q.x, q.z * q.z) - 1.0f) < 1e-3f) {
+            // origin on the wall: q_x^2 + q_z^2 == 1 exactly, c has no cancellation; Vieta for the near root
+            float h = fmaf(os.x, d.x, os.z * d.z);  // b / 2
+            float c = fmaf(2.0f, fmaf(q.x, dq.x, q.z * dq.z), fmaf(dq.x, dq.x, dq.z * dq.z));
+            float disc = fmaf(h, h, -(a * c));
+            if (disc < 0.0f) return;  // cylinder.rs:140-142 returns WITHOUT testing the caps
+            float sq = sqrtf(disc);
+            float qq = -(h + copysignf(sq, h));
+            float ta = qq / a;
+            float tb = (qq != 0.0f) ? c / qq : ta;
+            t0 = fminf(ta, tb), t1 = fmaxf(ta, tb);
+        } else {
+            // the sphere_foot construction in the xz plane
+            float tc, half;
+            V3 l;
+            if (!sphere_foot(v3(os.x, 0.0f, os.z), v3(d.x, 0.0f, d.z), a, tc, l, half)) return;
+            t0 = tc - half, t1 = tc + half;
+        }
+        float y0 = fmaf(t0, d.y, os.y);
+        if (ymin < y0 && y0 < ymax) r.t[0] = t0;
+        float y1 = fmaf(t1, d.y, os.y);
+        if (ymin < y1 && y1 < ymax) r.t[1] = t1;
+    }
+    if (!closed || approx(d.y, 0.0f)) return;  // cylinder.rs:192
+    float nlo, nhi;
+    if (self) {
+        nlo = (ymin - q.y) - dq.y;
+        nhi = (ymax - q.y) - dq.y;
+    } else {
+        nlo = ymin - o.y;
+        nhi = ymax - o.y;
+    }
+    float t = nlo / d.y;
+    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) r.t[2] = t;
+    t = nhi / d.y;
+    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) r.t[3] = t;
+}
+
+// triangle.rs:104-133 (Moller-Trumbore); e = {v0, e0, e1}
+RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Hits& r) {
+    r.n = 1;
+    r.t[0] = RT_NOHIT;
+    V3 dir_cross_e1 = cross(d, e1);
+    float det = dot(e0, dir_cross_e1);
+    if (fabsf(det) <= kEps) return;
+    float f = 1.0f / det;
+    V3 p0 = o - v0;
+    float u = f * dot(p0, dir_cross_e1);
+    if (!(u >= 0.0f && u <= 1.0f)) return;
+    V3 oxe0 = cross(p0, e0);
+    float v = f * dot(d, oxe0);
+    if (v < 0.0f || (u + v) > 1.0f) return;
+    r.t[0] = f * dot(e1, oxe0);
+    r.u = u;
+    r.v = v;
+}
+
+// Dispatch: world ray -> object space (shape.rs:79-81, ray.rs:17-22) -> primitive test.
+RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Hits& r) {
+    r.u = 0.0f, r.v = 0.0f;
+    switch (p.type) {
+        case PRIM_PLANE: {
+            float oy = self ? ray.dq.y : fmaf(p.inv[4], ray.o.x, fmaf(p.inv[5], ray.o.y, fmaf(p.inv[6], ray.o.z, p.inv[7])));
+            float dy = fmaf(p.inv[4], ray.d.x, fmaf(p.inv[5], ray.d.y, p.inv[6] * ray.d.z));
+            isect_plane(oy, dy, r);
+            break;
+        }
+        case PRIM_SPHERE: {
+            V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
+            isect_sphere(o, d, self, ray.q, ray.dq, r);
+            break;
+        }
+        case PRIM_CUBE: {
+            V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
+            isect_cube(o, d, self, ray.q, ray.dq, r);
+            break;
+        }
+        case PRIM_CYLINDER: {
+            V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
+            const float* e = extras[p.extra].f;
+            isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, r);
+            break;
+        }
+        default: {  // PRIM_TRIANGLE, PRIM_SMOOTH
+            V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
+            if (self) o = ray.q + ray.dq;
+            const float* e = extras[p.extra].f;
+            isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), r);
+            break;
+        }
+    }
+}
+
+// Group box test on the WORLD ray (group.rs:107, bounding_box.rs:81-84): hit iff tmin < tmax on
+// the whole line.  The device boxes are widened by a few ulps at upload so FP32 rounding cannot
+// cull a child the f64 test would have entered.
+RT_HD bool node_hit(const DNode& n, V3 o, V3 d) {
+    float tmin, tmax;
+    isect_box(v3(n.mn[0], n.mn[1], n.mn[2]) - o, v3(n.mx[0], n.mx[1], n.mx[2]) - o, d, tmin, tmax);
+    return tmin < tmax;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hit preparation: intersection.rs:40-69 + shape.rs:83-96,118-137 + per-shape normal_at.
+struct HitInfo {
+    V3 p;        // world hit point  (ray.position(t))
+    V3 n;        // world normal, flipped towards the eye
+    V3 eye;      // -direction
+    V3 q;        // snapped object-space hit point
+    V3 dq;       // object-space offset of over_point: eps * inv_linear * n   (under_point: -dq)
+    bool inside;
+};
+
+RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, float t, float hu, float hv) {
+    HitInfo h;
+    V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
+    if (self) o = ray.q + ray.dq;
+    V3 q = madd(d, t, o);
+    V3 nobj;
+    switch (p.type) {
+        case PRIM_SPHERE: {  // sphere.rs:74-76 — hit point from the perpendicular foot, snapped onto the unit sphere
+            float tc, half;
+            V3 l;
+            sphere_foot(o, d, dot(d, d), tc, l, half);
+            q = normalize(madd(d, (t < tc) ? -half : half, l));
+            nobj = q;
+            break;
+        }
+        case PRIM_PLANE:  // plane.rs:53-55
+            q.y = 0.0f;
+            nobj = v3(0.0f, 1.0f, 0.0f);
+            break;
+        case PRIM_CUBE: {  // cube.rs:125-141: exact max, then approx tie order x, y, z
+            float ax = fabsf(q.x), ay = fabsf(q.y), az = fabsf(q.z);
+            float mc = fmaxf(ax, fmaxf(ay, az));
+            if (approx(mc, ax)) {
+                q.x = copysignf(1.0f, q.x);
+                nobj = v3(q.x, 0.0f, 0.0f);
+            } else if (approx(mc, ay)) {
+                q.y = copysignf(1.0f, q.y);
+                nobj = v3(0.0f, q.y, 0.0f);
+            } else {
+                q.z = copysignf(1.0f, q.z);
+                nobj = v3(0.0f, 0.0f, q.z);
+            }
+            break;
+        }
+        case PRIM_CYLINDER: {  // cylinder.rs:172-184
+            const float* e = extras[p.extra].f;
+            float dist = fmaf(q.x, q.x, q.z * q.z);
+            float top = e[1] - kEps, bot = e[0] + kEps;
+            if (dist < 1.0f && (approx(q.y, top) || q.y > top)) {
+                q.y = e[1];
+                nobj = v3(0.0f, 1.0f, 0.0f);
+            } else if (dist < 1.0f && (approx(q.y, bot) || q.y < bot)) {
+                q.y = e[0];
+                nobj = v3(0.0f, -1.0f, 0.0f);
+            } else {
+                float tc, half;
+                V3 l;
+                V3 d2 = v3(d.x, 0.0f, d.z);
+                sphere_foot(v3(o.x, 0.0f, o.z), d2, dot(d2, d2), tc, l, half);
+                V3 w = madd(d2, (t < tc) ? -half : half, l);
+                float s = 1.0f / sqrtf(fmaf(w.x, w.x, w.z * w.z));
+                q.x = w.x * s, q.z = w.z * s;
+                nobj = v3(q.x, 0.0f, q.z);
+            }
+            break;
+        }
+        case PRIM_TRIANGLE: {  // triangle.rs:135-137
+            const float* e = extras[p.extra].f;
+            nobj = v3(e[9], e[10], e[11]);
+            break;
+        }
+        default: {  // smooth_triangle.rs:26-33
+            const float* e = extras[p.extra].f;
+            V3 n0 = v3(e[12], e[13], e[14]), n1 = v3(e[15], e[16], e[17]), n2 = v3(e[18], e[19], e[20]);
+            nobj = n1 * hu + n2 * hv + n0 * (1.0f - hu - hv);
+            break;
+        }
+    }
+    V3 n = normalize(xform_normal(p.inv, nobj));
+    h.eye = neg(ray.d);
+    h.inside = dot(n, h.eye) < 0.0f;  // intersection.rs:48
+    if (h.inside) n = neg(n);
+    h.n = n;
+    h.p = madd(ray.d, t, ray.o);
+    h.q = q;
+    h.dq = xform_vector(p.inv, n) * kEps;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pattern.rs:58-96, evaluated at the object-space over_point (q + dq)
+RT_HD V3 pattern_color(const DPattern& pat, V3 obj_point) {
+    V3 a = v3(pat.a[0], pat.a[1], pat.a[2]);
+    if (pat.type == PAT_SOLID) return a;
+    V3 b = v3(pat.b[0], pat.b[1], pat.b[2]);
+    V3 pp = xform_point(pat.inv, obj_point);
+    switch (pat.type) {
+        case PAT_STRIPE: return fabsf(fmodf(floorf(pp.x), 2.0f)) <= kEps ? a : b;
+        case PAT_GRADIENT: return a + (b - a) * (pp.x - floorf(pp.x));
+        case PAT_RING: return fabsf(fmodf(floorf(sqrtf(fmaf(pp.x, pp.x, pp.z * pp.z))), 2.0f)) <= kEps ? a : b;
+        default: return fabsf(fmodf(floorf(pp.x) + floorf(pp.y) + floorf(pp.z), 2.0f)) <= kEps ? a : b;
+    }
+}
+
+// material.rs:138-159 for ONE light cell: returns (light . normal) and the specular factor, both
+// already gated (0 when the reference skips them).
+RT_HD void phong_cell(V3 cell, V3 point, V3 n, V3 eye, float shininess, float& ldn_out, float& spec_out) {
+    V3 lv = cell - point;
+    float len = sqrtf(dot(lv, lv));
+    V3 lightv = (fabsf(len) <= kEps) ? v3(0.0f, 0.0f, 0.0f) : lv * (1.0f / len);  // normalize().unwrap_or(0)
+    float ldn = dot(lightv, n);
+    ldn_out = 0.0f;
+    spec_out = 0.0f;
+    if (approx(ldn, 0.0f) || ldn > 0.0f) {  // float::ge(light_dot_normal, 0.0)
+        ldn_out = ldn;
+        V3 ml = neg(lightv);
+        V3 rv = ml - n * 2.0f * dot(ml, n);  // (-lightv).reflect(normalv)
+        float rde = dot(rv, eye);
+        if (rde > 0.0f) {
+            // factor = (reflect . eye)^shininess (material.rs:150-153).  x^200 turns the 1e-7 absolute
+            // rounding error of an FP32 dot product of two unit vectors into 2e-5 RELATIVE error on
+            // highlights whose value exceeds 1, so cos(theta) is taken from the cross product
+            // instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full relative accuracy in
+            // (1 - cos), and the power is exp(shininess/2 * log1p(-sin^2)).
+            V3 cx = cross_exact(rv, eye);
+            float sin2 = dot(cx, cx) / (dot(rv, rv) * dot(eye, eye));
+            sin2 = fminf(sin2, 1.0f);
+            spec_out = (sin2 < 0.25f) ? expf(0.5f * shininess * log1pf(-sin2)) : powf(rde, shininess);
+        }
+    }
+}
+
+// intersection.rs:124-141
+RT_HD float schlick(V3 eye, V3 n, float n1, float n2) {
+    float c = dot(eye, n);
+    if (n1 > n2) {
+        float r = n1 / n2;
+        float sin2_t = r * r * (1.0f - c * c);
+        if (sin2_t > 1.0f) return 1.0f;
+        c = sqrtf(1.0f - sin2_t);
+    }
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    float k = 1.0f - c;
+    float k2 = k * k;
+    return r0 + (1.0f - r0) * (k2 * k2 * k);
+}
+
+// world.rs:113-125: returns false under total internal reflection
+RT_HD bool refract_dir(V3 eye, V3 n, float n1, float n2, V3& dir) {
+    float r = n1 / n2;
+    float cos_i = dot(eye, n);
+    float sin2_t = r * r * (1.0f - cos_i * cos_i);
+    if (sin2_t > 1.0f) return false;
+    float cos_t = sqrtf(1.0f - sin2_t);
+    dir = n * (r * cos_i - cos_t) - eye * r;
+    return true;
+}
+
+// camera.rs:210-228.  direction = normalize(inv_linear * (wx, wy, -1)) — identical to
+// normalize(pixel - origin) in exact arithmetic, without the cancellation for far cameras.
+RT_HD void camera_ray(const DCamera& c, uint32_t x, uint32_t y, V3& origin, V3& dir) {
+    float wx = c.half_width - (static_cast<float>(x) + 0.5f) * c.pixel_size;
+    float wy = c.half_height - (static_cast<float>(y) + 0.5f) * c.pixel_size;
+    origin = v3(c.inv[3], c.inv[7], c.inv[11]);
+    dir = normalize(xform_vector(c.inv, v3(wx, wy, -1.0f)));
+}
+
+// Jitter hash shared bit-for-bit with oracle/rt_oracle.hpp (counter_jitter).
+RT_HD uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+RT_HD uint32_t jitter_pixel_key(uint32_t seed, uint32_t pixel) { return fmix32(pixel ^ (seed * 0x9E3779B9u)); }
+RT_HD float counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, uint32_t axis) {
+    uint32_t k = (node << 24) | (light << 16) | (cell << 1) | axis;
+    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u);
+    return static_cast<float>(h >> 24) / 255.0f;
+}
+
+// light.rs:211-216
+RT_HD V3 point_on_light(const DLight& l, uint32_t u, uint32_t v, float ju, float jv) {
+    V3 c = v3(l.pos[0], l.pos[1], l.pos[2]);
+    V3 uv = v3(l.uvec[0], l.uvec[1], l.uvec[2]), vv = v3(l.vvec[0], l.vvec[1], l.vvec[2]);
+    return c + uv * (static_cast<float>(u) + ju) + vv * (static_cast<float>(v) + jv);
+}
+
+// canvas.rs:37-39: `(c * 255.0) as u8`
+RT_HD uint8_t quantize_u8(float c) {
+    float v = c * 255.0f;
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return static_cast<uint8_t>(v);
+}
+
+}  // namespace rtk

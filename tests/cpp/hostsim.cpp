@@ -1,0 +1,252 @@
+// hostsim.cpp — TEST-ONLY scalar executor of the kernel's FP32 per-lane arithmetic (rt_math.h).
+//
+// This container has no GPU, so the FP32-vs-f64 parity of the kernel's formulation (snapped
+// self-intersection, stable sphere discriminant, order-free n1/n2, iterative ray stack) is
+// debugged here: the same rt_math.h functions the HIP kernel calls are compiled with g++ and
+// driven by a plain scalar loop.  Wave-level orchestration (ballots, cooperative area-light
+// sampling, the threaded traversal's uniform jumps) is NOT simulated — that is covered by the
+// `-m gpu` tests.  Never linked into the product library; the product has no CPU path.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../raytracer_amd/csrc/rt_pack.h"
+
+using namespace rtk;
+
+namespace {
+
+struct Sim {
+    PackedScene ps;
+    DCamera cam;
+    uint32_t max_depth, jitter_mode, seed;
+};
+
+struct Closest {
+    uint32_t prim;
+    float t, u, v;
+};
+
+template <class Visit>
+void traverse(const Sim& s, const Ray& ray, Visit&& visit) {
+    uint32_t i = 0;
+    while (i < s.ps.n_items) {
+        DItem it = s.ps.items[i];
+        if (it.ref & kItemNode) {
+            i = node_hit(s.ps.nodes[it.ref & ~kItemNode], ray.o, ray.d) ? i + 1 : it.next;
+            continue;
+        }
+        const DPrim& p = s.ps.prims[it.ref];
+        Hits h;
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == it.ref, h);
+        if (!visit(it.ref, p, h)) return;
+        ++i;
+    }
+}
+
+Closest closest_hit(const Sim& s, const Ray& ray) {
+    Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
+    traverse(s, ray, [&](uint32_t prim, const DPrim&, const Hits& h) {
+        for (int k = 0; k < h.n; ++k)
+            if (closer_hit(h.t[k], c.t)) c = Closest{prim, h.t[k], h.u, h.v};
+        return true;
+    });
+    return c;
+}
+
+// world.rs:73-92: shadowed iff the nearest positive hit is closer than the light
+bool occluded(const Sim& s, const Ray& ray, float dist) {
+    bool occ = false;
+    traverse(s, ray, [&](uint32_t, const DPrim&, const Hits& h) {
+        for (int k = 0; k < h.n; ++k)
+            if (h.t[k] > 0.0f && h.t[k] < dist) occ = true;
+        return !occ;
+    });
+    return occ;
+}
+
+// intersection.rs:71-103 without the sorted list: a primitive is a "container" at the hit iff an
+// odd number of its intersections precede the hit; `visited.last()` is the container whose last
+// crossing before the hit has the largest t.
+void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2) {
+    float best_t = -INFINITY, best_ior = 1.0f;
+    bool have_best = false, hit_in = false;
+    float hit_last = -INFINITY;
+    traverse(s, ray, [&](uint32_t prim, const DPrim& p, const Hits& h) {
+        int cnt = 0;
+        float last = -INFINITY;
+        int skip = -1;
+        if (prim == hit_prim) {  // the hit itself = its intersection closest to t_hit
+            float bd = INFINITY;
+            for (int k = 0; k < h.n; ++k)
+                if (fabsf(h.t[k] - t_hit) < bd) bd = fabsf(h.t[k] - t_hit), skip = k;
+        }
+        for (int k = 0; k < h.n; ++k) {
+            if (k == skip) continue;
+            if (precedes_hit(h.t[k], t_hit, prim, hit_prim)) ++cnt, last = fmaxf(last, h.t[k]);
+        }
+        if (cnt & 1) {
+            if (prim == hit_prim) hit_in = true, hit_last = last;
+            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = p.ior;
+        }
+        return true;
+    });
+    float excl = have_best ? best_ior : 1.0f;
+    if (hit_in) {
+        n1 = (!have_best || hit_last > best_t) ? hit_ior : best_ior;
+        n2 = excl;
+    } else {
+        n1 = excl;
+        n2 = hit_ior;
+    }
+}
+
+struct PathNode {
+    Ray ray;
+    V3 w;
+    uint32_t depth, node;
+};
+
+V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
+    V3 acc = v3(0, 0, 0);
+    if (s.ps.n_lights == 0) return acc;  // world.rs:44: fold over no lights == BLACK
+    uint32_t pixel_key = jitter_pixel_key(s.seed, y * s.cam.hsize + x);
+    PathNode stack[16];
+    int sp = 0;
+    PathNode cur;
+    camera_ray(s.cam, x, y, cur.ray.o, cur.ray.d);
+    cur.ray.self = kNoPrim, cur.ray.q = v3(0, 0, 0), cur.ray.dq = v3(0, 0, 0);
+    cur.w = v3(1, 1, 1), cur.depth = s.max_depth, cur.node = 0;
+    const float nl = static_cast<float>(s.ps.n_lights);
+    for (;;) {
+        bool alive = false;
+        Closest c = closest_hit(s, cur.ray);
+        if (c.prim != kNoPrim) {
+            const DPrim& p = s.ps.prims[c.prim];
+            const DMaterial& m = s.ps.mats[p.material];
+            HitInfo h = prepare_hit(p, s.ps.extras.data(), cur.ray, cur.ray.self == c.prim, c.t, c.u, c.v);
+            V3 over = h.p + h.n * kEps;
+            V3 pc = pattern_color(s.ps.pats[m.pattern], h.q + h.dq);
+            V3 surface = v3(0, 0, 0);
+            for (uint32_t li = 0; li < s.ps.n_lights; ++li) {
+                const DLight& l = s.ps.lights[li];
+                V3 lc = v3(l.color[0], l.color[1], l.color[2]);
+                V3 ec = pc * lc;
+                uint32_t cells = l.usteps * l.vsteps;
+                uint32_t lit = 0;
+                float sum_d = 0.0f, sum_s = 0.0f;
+                for (uint32_t cell = 0; cell < cells; ++cell) {
+                    uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
+                    float ju = 0.5f, jv = 0.5f;
+                    if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER) {
+                        ju = counter_jitter(pixel_key, cur.node, li, cell, 0);
+                        jv = counter_jitter(pixel_key, cur.node, li, cell, 1);
+                    }
+                    V3 lp = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, ju, jv) : v3(l.pos[0], l.pos[1], l.pos[2]);
+                    V3 tl = lp - over;
+                    float dist = sqrtf(dot(tl, tl));
+                    bool shadowed = false;
+                    if (!(fabsf(dist) <= kEps)) {  // null vector => not shadowed (world.rs:77-81)
+                        Ray sr;
+                        sr.o = over, sr.d = tl * (1.0f / dist), sr.self = c.prim, sr.q = h.q, sr.dq = h.dq;
+                        shadowed = occluded(s, sr, dist);
+                    }
+                    if (!shadowed) ++lit;
+                    V3 centre = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, 0.5f, 0.5f) : lp;
+                    float ldn, spec;
+                    phong_cell(centre, over, h.n, h.eye, m.shininess, ldn, spec);
+                    sum_d += ldn, sum_s += spec;
+                }
+                float intensity = static_cast<float>(lit) * l.inv_samples;
+                V3 shade = ec * (m.diffuse * sum_d) + lc * (m.specular * sum_s);
+                surface = surface + ec * m.ambient + shade * (l.inv_samples * intensity);
+            }
+            acc = acc + cur.w * surface;
+            if (debug)
+                std::printf("  [sim] node=%u depth=%u t=%.9g prim=%u type=%u p=(%.9g %.9g %.9g) n=(%.9g %.9g %.9g) inside=%d surf=(%.9g %.9g %.9g) w=(%.6g %.6g %.6g)\n",
+                            cur.node, cur.depth, c.t, c.prim, p.type, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, int(h.inside), surface.x,
+                            surface.y, surface.z, cur.w.x, cur.w.y, cur.w.z);
+
+            // children (world.rs:59-69,94-133); the per-light duplication becomes a factor n_lights
+            bool want_refl = !(fabsf(m.reflectivity) <= kEps) && cur.depth > 0;
+            bool want_refr = !(fabsf(m.transparency) <= kEps) && cur.depth > 0;
+            float n1 = 1.0f, n2 = 1.0f;
+            bool use_schlick = (m.reflectivity * m.transparency) > 0.0f;
+            if (cur.depth > 0 && m.transparency > 0.0f) containers(s, cur.ray, c.prim, c.t, m.ior, n1, n2);
+            if (debug) std::printf("        n1=%.6g n2=%.6g\n", n1, n2);
+            V3 rdir = v3(0, 0, 0);
+            if (want_refr && !refract_dir(h.eye, h.n, n1, n2, rdir)) want_refr = false;
+            float fr = use_schlick ? schlick(h.eye, h.n, n1, n2) : 0.0f;
+            float k_refl = nl * m.reflectivity * (use_schlick ? fr : 1.0f);
+            float k_refr = nl * m.transparency * (use_schlick ? (1.0f - fr) : 1.0f);
+            PathNode refl, refr;
+            if (want_refl) {
+                refl.ray.o = over, refl.ray.d = cur.ray.d - h.n * 2.0f * dot(cur.ray.d, h.n);
+                refl.ray.self = c.prim, refl.ray.q = h.q, refl.ray.dq = h.dq;
+                refl.w = cur.w * k_refl, refl.depth = cur.depth - 1, refl.node = 2 * cur.node + 1;
+            }
+            if (want_refr) {
+                refr.ray.o = h.p - h.n * kEps, refr.ray.d = rdir;
+                refr.ray.self = c.prim, refr.ray.q = h.q, refr.ray.dq = neg(h.dq);
+                refr.w = cur.w * k_refr, refr.depth = cur.depth - 1, refr.node = 2 * cur.node + 2;
+            }
+            if (want_refl && want_refr) {
+                stack[sp++] = refr;
+                cur = refl;
+                alive = true;
+            } else if (want_refl) {
+                cur = refl;
+                alive = true;
+            } else if (want_refr) {
+                cur = refr;
+                alive = true;
+            }
+        }
+        if (!alive) {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    return acc;
+}
+
+}  // namespace
+
+extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
+                              float* rgb_out, char* err_out, int err_cap) {
+    Sim s;
+    std::string err;
+    int rc = pack_scene(desc, s.ps, err);
+    if (rc != RT_OK) {
+        if (err_out && err_cap > 0) std::snprintf(err_out, static_cast<size_t>(err_cap), "%s", err.c_str());
+        return rc;
+    }
+    s.cam = pack_camera(*camera);
+    s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
+    s.jitter_mode = options ? options->jitter_mode : 0u;
+    s.seed = options ? options->seed : 0u;
+    const uint32_t W = camera->hsize, H = camera->vsize;
+    if (const char* dbg = std::getenv("HOSTSIM_DEBUG_PIXEL")) {
+        unsigned dx = 0, dy = 0;
+        if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && dx < W && dy < H) trace_pixel(s, dx, dy, true);
+    }
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 4;
+    if (nthreads > 8) nthreads = 8;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t] {
+            for (uint32_t y = t; y < H; y += nthreads)
+                for (uint32_t x = 0; x < W; ++x) {
+                    V3 c = trace_pixel(s, x, y);
+                    float* o = rgb_out + (static_cast<size_t>(y) * W + x) * 3;
+                    o[0] = c.x, o[1] = c.y, o[2] = c.z;
+                }
+        });
+    for (auto& th : pool) th.join();
+    return RT_OK;
+}

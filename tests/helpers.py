@@ -1,0 +1,119 @@
+"""ctypes access to the TEST infrastructure: the f64 oracle (oracle/_build/liboracle.so) and the
+scalar FP32 host simulator of the kernel arithmetic (tests/cpp/_build/libhostsim.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use these.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+ORACLE_KAT = os.path.join(ROOT, "oracle", "_build", "oracle_kat")
+HOSTSIM_SO = os.path.join(ROOT, "tests", "cpp", "_build", "libhostsim.so")
+
+JITTER_CENTER, JITTER_COUNTER, JITTER_THREAD_RNG = 0, 1, 2
+
+# (scene, default parity resolution) — 16:9 like the examples
+SCENES = [
+    "test_world", "checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
+    "glass_sphere_checkered_floor_aerial_view", "multiple_glass_and_metallic_spheres",
+    "cover_image", "cover_image_area", "shapes_zoo",
+]
+
+_oracle = None
+_hostsim = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_render_example.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_probe_pixels.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_quantize_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_quantize_u8.restype = None
+        L.oracle_counter_jitter.argtypes = [C.c_uint32] * 6
+        L.oracle_counter_jitter.restype = C.c_double
+        L.oracle_scene_name.restype = C.c_char_p
+        _oracle = L
+    return _oracle
+
+
+ORACLE_STAT_NAMES = ["primary", "reflect", "refract", "shadow", "shaded_hits", "light_cells", "pattern_lookups",
+                     "tests_cube", "tests_cylinder", "tests_group_box", "tests_plane", "tests_smooth_triangle",
+                     "tests_sphere", "tests_triangle"]
+
+
+def oracle_render(name: str, width: int, height: int, jitter: int = JITTER_CENTER, seed: int = 0, threads: int = 0,
+                  rows: Optional[Tuple[int, int]] = None, want_stats: bool = False):
+    """f64 oracle render.  Returns (rgb[h, w, 3] float64, stats dict or None, seconds)."""
+    L = oracle()
+    rgb = np.zeros((height, width, 3), dtype=np.float64)
+    stats = np.zeros(14, dtype=np.uint64)
+    sec = C.c_double()
+    r0, r1 = rows if rows else (0, 0)
+    rc = L.oracle_render_example(name.encode(), width, height, jitter, seed, threads, r0, r1, rgb.ctypes.data,
+                                 stats.ctypes.data if want_stats else None, C.byref(sec))
+    if rc != 0:
+        raise RuntimeError(L.oracle_last_error().decode())
+    sd = dict(zip(ORACLE_STAT_NAMES, (int(v) for v in stats))) if want_stats else None
+    return rgb, sd, sec.value
+
+
+def oracle_probe(name: str, width: int, height: int, xy: np.ndarray, jitter: int = JITTER_CENTER, seed: int = 0) -> np.ndarray:
+    L = oracle()
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = np.zeros((xy.shape[0], 3), dtype=np.float64)
+    rc = L.oracle_probe_pixels(name.encode(), width, height, jitter, seed, xy.ctypes.data, xy.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(L.oracle_last_error().decode())
+    return out
+
+
+def oracle_quantize(rgb: np.ndarray) -> np.ndarray:
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    out = np.empty(rgb.shape, dtype=np.uint8)
+    oracle().oracle_quantize_u8(rgb.ctypes.data, rgb.size, out.ctypes.data)
+    return out
+
+
+def hostsim():
+    global _hostsim
+    if _hostsim is None:
+        L = C.CDLL(HOSTSIM_SO)
+        L.hostsim_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        _hostsim = L
+    return _hostsim
+
+
+def hostsim_render(example, options=None) -> np.ndarray:
+    """Scalar FP32 execution of the kernel arithmetic on an ExampleScene (tests only)."""
+    cam = example.camera_desc.contents
+    out = np.zeros((cam.vsize, cam.hsize, 3), dtype=np.float32)
+    err = C.create_string_buffer(256)
+    rc = hostsim().hostsim_render(C.cast(example.scene_desc, C.c_void_p), C.cast(example.camera_desc, C.c_void_p),
+                                  C.cast(C.byref(options), C.c_void_p) if options is not None else None,
+                                  out.ctypes.data, err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
+def compare(test: np.ndarray, ref: np.ndarray, tol: float = 1e-4) -> dict:
+    """Per-channel absolute error summary of an f32 image against the f64 oracle image."""
+    d = np.abs(test.astype(np.float64) - ref)
+    bad = (d > tol).any(axis=-1)
+    return {
+        "max_abs": float(d.max()) if d.size else 0.0,
+        "bad_pixels": int(bad.sum()),
+        "pixels": int(bad.size),
+        "bad_frac": float(bad.mean()) if bad.size else 0.0,
+        "rmse": float(np.sqrt((d ** 2).mean())) if d.size else 0.0,
+    }
