@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s and frame ms of the MI355X render path (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME --width W --height H]
+
+A "step" is ONE FRAME of the workload: Camera::render of the scene at the config's resolution,
+scene tables and output image resident in HBM.  Default workload = BASELINE.json configs[1]:
+examples/striped_sphere_multiple_lights at 1920x1080 (as the example file is written: two AREA
+lights, 8x8 and 4x4 cells, jittered with the counter RNG, seed 0).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU, RCCL) the SAME frame is split into interleaved bands of 8
+pixel rows (band b -> rank b mod N), every rank renders its bands with the scene replicated, and the
+bands are gathered to rank 0 and re-interleaved there — all inside the timed region ("strong" scaling).
+
+Rank 0 prints ONE JSON line.  `value` = unique rays traced per second over the whole job
+(primary + reflection + refraction + shadow; the reference's own count is the same for this
+workload because nothing in it is reflective).  `roofline` compares the ALGORITHMIC FP32 flop rate of
+the render kernel (raytracer_amd/flopmodel.py) with the FP32 vector peak; the kernel
+time is measured with events on the stream the kernel is launched on.  `cpu_baseline` is the f64
+oracle (a restatement of the reference algorithm, NOT the Rust binary) timed on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from raytracer_amd import ExampleScene, RtOptions, Scene, band_rows  # noqa: E402
+from raytracer_amd import flopmodel  # noqa: E402
+
+WORKLOADS = {  # BASELINE.json configs (the scene files as written)
+    "striped_sphere_multiple_lights": (1920, 1080),
+    "checkered_walls_metallic_sphere": (1280, 720),
+    "glass_sphere_checkered_floor_aerial_view": (1920, 1080),
+    "multiple_glass_and_metallic_spheres": (3840, 2160),
+    "cover_image": (3840, 2160),
+    "cover_image_area": (3840, 2160),
+    "shapes_zoo": (1920, 1080),
+}
+BAND_ROWS = 8
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="striped_sphere_multiple_lights", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--jitter", default="counter", choices=["counter", "center"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(name: str, width: int, height: int, jitter: int, seed: int, target_s: float):
+    """The f64 oracle on this host: bounded sample of the same workload (checker/baseline only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    cores = max(1, min(cores, os.cpu_count() or 1))
+    mid = height // 2
+    _, st, sec = H.oracle_render(name, width, height, jitter=jitter, seed=seed, threads=cores,
+                                 rows=(mid - 4, mid + 4), want_stats=True)  # calibration band
+    per_row = max(sec / 8.0, 1e-6)
+    rows = int(min(height, max(8, target_s / per_row)))
+    r0 = max(0, mid - rows // 2)
+    r1 = min(height, r0 + rows)
+    _, st, sec = H.oracle_render(name, width, height, jitter=jitter, seed=seed, threads=cores, rows=(r0, r1),
+                                 want_stats=True)
+    rays = st["primary"] + st["reflect"] + st["refract"] + st["shadow"]
+    return {
+        "value": rays / sec / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"rows {r0}..{r1} of {height} at {width}x{height} ({rays} reference-equivalent rays in {sec:.2f} s; "
+                  f"f64 C++ restatement of the reference algorithm, RENDER_THREADS={cores})",
+        "frame_ms_extrapolated": sec * 1e3 * height / max(1, r1 - r0),
+    }, st
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    width, height = WORKLOADS[args.workload]
+    width, height = args.width or width, args.height or height
+    ex = ExampleScene(args.workload, width, height)
+    scene = Scene(ex.scene_desc, local_rank)
+    n_lights = int(ex.scene_desc.contents.n_lights)
+
+    opt = RtOptions()
+    opt.jitter_mode = 1 if args.jitter == "counter" else 0
+    opt.seed = args.seed
+    if world > 1:
+        opt.tile_rows, opt.tile_first, opt.tile_stride = BAND_ROWS, rank, world
+    my_rows = scene.output_rows(ex.camera_desc, opt)
+    max_rows = len(band_rows(height, BAND_ROWS, 0, world)) if world > 1 else height
+    local = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
+    final = perm = gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        pos = np.empty(height, dtype=np.int64)
+        for r in range(world):
+            rows_r = band_rows(height, BAND_ROWS, r, world)
+            pos[rows_r] = r * max_rows + np.arange(len(rows_r))
+        perm = torch.from_numpy(pos).to(dev)
+        final = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+
+    def frame():
+        stream = torch.cuda.current_stream().cuda_stream
+        scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ray / work counters of this rank's share (untimed, instrumented kernel variant)
+    _, st = scene.render(ex.camera_desc, opt, stats=True)
+    counts = torch.tensor([st.primary_rays, st.reflection_rays, st.refraction_rays, st.shadow_rays, st.shaded_hits,
+                           st.light_cells, st.pattern_lookups, st.container_passes], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    names = ["primary_rays", "reflection_rays", "refraction_rays", "shadow_rays", "shaded_hits", "light_cells",
+             "pattern_lookups", "container_passes"]
+    total = dict(zip(names, (int(v) for v in counts.tolist())))
+    mine = dict(zip(names, (st.primary_rays, st.reflection_rays, st.refraction_rays, st.shadow_rays, st.shaded_hits,
+                            st.light_cells, st.pattern_lookups, st.container_passes)))
+    total_rays = total["primary_rays"] + total["reflection_rays"] + total["refraction_rays"] + total["shadow_rays"]
+
+    for _ in range(args.warmup):
+        frame()
+    sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        stream = torch.cuda.current_stream().cuda_stream
+        ev[k][0].record()
+        scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        base, ost = (None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            base, ost = cpu_baseline(args.workload, width, height, opt.jitter_mode, opt.seed, args.cpu_seconds)
+        cost = flopmodel.ray_cost(ex.scene_desc, ost)
+        flops = flopmodel.frame_flops(mine, n_lights, cost)  # rank 0's launch
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/sec (primary+secondary) and frame ms at 1080p/4K, 1 and 8 MI355X",
+            "value": total_rays / (ms_per_step * 1e-3) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"examples/{args.workload} at {width}x{height}, jitter={args.jitter} seed={args.seed}, "
+                            f"RECURSION_DEPTH=5",
+                "partition": "whole frame on one GPU" if world == 1 else
+                             f"interleaved {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0",
+                "rays_per_frame": total_rays, "rays_by_kind": total,
+            },
+            "frame_ms": ms_per_step,
+            "kernel_ms": kernel_ms,
+            "roofline": {
+                "bound": "valu_fp32", "achieved": achieved, "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / flopmodel.PEAK_FP32_TFLOPS,
+                "frac_of_unpacked_peak": achieved / flopmodel.PEAK_FP32_UNPACKED_TFLOPS,
+                "traffic": None,
+                "algorithmic_flop_per_launch": flops, "flop_per_ray_intersection": cost,
+                "kernel": "render_kernel<false>", "kernel_ms": kernel_ms,
+            },
+        }
+        if base is not None:
+            out["cpu_baseline"] = base
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ from .capi import (  # noqa: F401
     RtSceneDesc,
     RtStats,
     Scene,
+    band_rows,
     example_names,
     lib,
     lib_path,
@@ -23,5 +24,5 @@ from .capi import (  # noqa: F401
 
 __all__ = [
     "ExampleScene", "RtCameraDesc", "RtError", "RtOptions", "RtSceneDesc", "RtStats", "Scene",
-    "example_names", "lib", "lib_path", "quantize_u8", "scenes_lib",
+    "band_rows", "example_names", "lib", "lib_path", "quantize_u8", "scenes_lib",
 ]

@@ -208,6 +208,19 @@ class Scene:
             pass
 
 
+def band_rows(vsize: int, tile_rows: int, tile_first: int = 0, tile_stride: int = 1) -> np.ndarray:
+    """Global image row of every packed output row of a call with these rt_options tile fields
+    (index arithmetic only — the rule documented on rt_options in include/rt_amd.h)."""
+    if tile_rows == 0:
+        return np.arange(vsize, dtype=np.int64)
+    rows = []
+    b = tile_first
+    while b * tile_rows < vsize:
+        rows.extend(range(b * tile_rows, min((b + 1) * tile_rows, vsize)))
+        b += tile_stride
+    return np.asarray(rows, dtype=np.int64)
+
+
 def quantize_u8(rgb: np.ndarray) -> np.ndarray:
     """Canvas::to_image on the GPU (rt_quantize_u8)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)

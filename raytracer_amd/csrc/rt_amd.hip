@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
             h = prepare_hit(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
             over = h.p + h.n * kEps;
             pc = pattern_color(sc.pats[m.pattern], h.q + h.dq);  // pattern at over_point (material.rs:127)
-            if (STATS) c_shaded++, c_pattern += sc.n_lights;
+            // the reference looks the pattern up once per light (material.rs:127); Solid costs nothing
+            if (STATS) c_shaded++, c_pattern += (sc.pats[m.pattern].type != PAT_SOLID) ? sc.n_lights : 0u;
         }
 
         // ---------------------------------------------------------------- shade (world.rs:43-58)

@@ -234,16 +234,25 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
         unsigned dx = 0, dy = 0;
         if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && dx < W && dy < H) trace_pixel(s, dx, dy, true);
     }
+    // Row bands exactly as rt_options documents them (tile_rows == 0: the whole image).
+    std::vector<uint32_t> rows;  // global row of each packed output row
+    {
+        const uint32_t tr = (options && options->tile_rows) ? options->tile_rows : H;
+        const uint32_t first = (options && options->tile_rows) ? options->tile_first : 0u;
+        const uint32_t stride = (options && options->tile_rows) ? (options->tile_stride ? options->tile_stride : 1u) : 1u;
+        for (uint64_t b = first; b * tr < H; b += stride)
+            for (uint64_t y = b * tr; y < (b + 1) * tr && y < H; ++y) rows.push_back(static_cast<uint32_t>(y));
+    }
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 4;
     if (nthreads > 8) nthreads = 8;
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nthreads; ++t)
         pool.emplace_back([&, t] {
-            for (uint32_t y = t; y < H; y += nthreads)
+            for (size_t r = t; r < rows.size(); r += nthreads)
                 for (uint32_t x = 0; x < W; ++x) {
-                    V3 c = trace_pixel(s, x, y);
-                    float* o = rgb_out + (static_cast<size_t>(y) * W + x) * 3;
+                    V3 c = trace_pixel(s, x, rows[r]);
+                    float* o = rgb_out + (r * W + x) * 3;
                     o[0] = c.x, o[1] = c.y, o[2] = c.z;
                 }
         });

@@ -95,8 +95,11 @@ def hostsim():
 
 def hostsim_render(example, options=None) -> np.ndarray:
     """Scalar FP32 execution of the kernel arithmetic on an ExampleScene (tests only)."""
+    from raytracer_amd import band_rows
     cam = example.camera_desc.contents
-    out = np.zeros((cam.vsize, cam.hsize, 3), dtype=np.float32)
+    nrows = cam.vsize if options is None else len(band_rows(cam.vsize, options.tile_rows, options.tile_first,
+                                                            max(1, options.tile_stride)))
+    out = np.zeros((nrows, cam.hsize, 3), dtype=np.float32)
     err = C.create_string_buffer(256)
     rc = hostsim().hostsim_render(C.cast(example.scene_desc, C.c_void_p), C.cast(example.camera_desc, C.c_void_p),
                                   C.cast(C.byref(options), C.c_void_p) if options is not None else None,
