@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from raytracer_amd import ExampleScene, RtOptions, Scene, band_rows  # noqa: E402
+from raytracer_amd import ExampleScene, RtOptions, Scene  # noqa: E402
+from raytracer_amd import partition  # noqa: E402
 from raytracer_amd import flopmodel  # noqa: E402
 
 WORKLOADS = {  # BASELINE.json configs (the scene files as written)
@@ -45,7 +46,7 @@ WORKLOADS = {  # BASELINE.json configs (the scene files as written; SURVEY.md §
     "cover_image_area": (3840, 2160),
     "shapes_zoo": (1920, 1080),
 }
-BAND_ROWS = 8
+BAND_ROWS = partition.BAND_ROWS
 
 
 def parse_args():
@@ -111,22 +112,17 @@ def main():
     scene = Scene(ex.scene_desc, local_rank)
     n_lights = int(ex.scene_desc.contents.n_lights)
 
-    opt = RtOptions()
-    opt.jitter_mode = 1 if args.jitter == "counter" else 0
-    opt.seed = args.seed
-    if world > 1:
-        opt.tile_rows, opt.tile_first, opt.tile_stride = BAND_ROWS, rank, world
-    my_rows = scene.output_rows(ex.camera_desc, opt)
-    max_rows = len(band_rows(height, BAND_ROWS, 0, world)) if world > 1 else height
+    base = RtOptions()
+    base.jitter_mode = 1 if args.jitter == "counter" else 0
+    base.seed = args.seed
+    opt = partition.rank_options(base, rank, world)
+    max_rows = partition.padded_rows(height, world)
+    assert scene.output_rows(ex.camera_desc, opt) <= max_rows
     local = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
     final = perm = gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(local) for _ in range(world)]
-        pos = np.empty(height, dtype=np.int64)
-        for r in range(world):
-            rows_r = band_rows(height, BAND_ROWS, r, world)
-            pos[rows_r] = r * max_rows + np.arange(len(rows_r))
-        perm = torch.from_numpy(pos).to(dev)
+        perm = torch.from_numpy(partition.gather_permutation(height, world)).to(dev)
         final = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
 
     def frame():

@@ -571,9 +571,11 @@ RT_HD V3 point_on_light(const DLight& l, uint32_t u, uint32_t v, float ju, float
 
 // canvas.rs:37-39: `(c * 255.0) as u8`
 RT_HD uint8_t quantize_u8(float c) {
-    float v = c * 255.0f;
-    if (!(v == v) || v <= 0.0f) return 0;
-    if (v >= 255.0f) return 255;
+    // the product in f64, as the reference forms it: an f32 product can round UP onto an integer the
+    // f64 product stays below (the kernel is HBM-bound, the f64 multiply is free)
+    double v = static_cast<double>(c) * 255.0;
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
     return static_cast<uint8_t>(v);
 }
 

@@ -1,0 +1,104 @@
+"""The kernel's FP32 arithmetic (raytracer_amd/csrc/rt_math.h), executed on the CPU by the test-only
+host simulator, against the f64 oracle and the golden vectors.  This is what can be checked about
+the device code in a container without a GPU; the `-m gpu` tests repeat it on the real kernel.
+
+Bar (north_star): per-channel |f32 - f64| <= TOL = 1e-4.  FP32 cannot meet it on EVERY pixel: colour
+is a discontinuous function of position at pattern edges, shadow edges, silhouettes and at exact
+ties (a ray hitting the line where two planes meet), so a 1e-6 difference in a hit point flips a
+whole pixel.  The tests therefore bound the FRACTION of pixels above TOL per scene (every offending
+class is listed in DESIGN.md) and require that nearly all PNG bytes agree to <= 1 LSB.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import ExampleScene, RtOptions
+
+TOL = 1e-4
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# max fraction of pixels with any channel off by more than TOL at 96x54 (edge pixels are a larger
+# share of a small image than of a 1080p one)
+BAD_FRAC = {
+    "test_world": 0.0,
+    "checkered_walls_metallic_sphere": 2e-3,
+    "striped_sphere_multiple_lights": 2e-3,
+    "glass_sphere_checkered_floor_aerial_view": 4e-3,  # + the x = -z symmetry plane: exact wall-corner ties
+    "multiple_glass_and_metallic_spheres": 4e-3,
+    "cover_image": 1e-3,
+    "cover_image_area": 1e-3,
+    "shapes_zoo": 2e-2,  # ring pattern aliasing at the horizon rows
+}
+
+
+def _png_lsb_frac(test, ref):
+    a = H.oracle_quantize(ref).astype(np.int16)
+    b = H.oracle_quantize(test.astype(np.float64)).astype(np.int16)
+    return float((np.abs(a - b) > 1).mean())
+
+
+@pytest.mark.parametrize("name", H.SCENES)
+def test_fp32_formulation_matches_golden_images(name):
+    ref = np.load(os.path.join(GOLDEN, "images.npz"))[name]
+    h, w, _ = ref.shape
+    ex = ExampleScene(name, w, h)
+    sim = H.hostsim_render(ex, RtOptions())
+    c = H.compare(sim, ref, TOL)
+    assert c["bad_frac"] <= BAD_FRAC[name], c
+    assert np.median(np.abs(sim - ref)) <= 1e-6
+    assert _png_lsb_frac(sim, ref) <= BAD_FRAC[name]
+
+
+@pytest.mark.parametrize("name", ["checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
+                                  "glass_sphere_checkered_floor_aerial_view", "cover_image_area", "shapes_zoo"])
+def test_counter_rng_jitter_is_shared_with_the_oracle(name):
+    """Same hash, same keys (seed, pixel, path node, light, cell, axis): stochastic scenes compare at the
+    deterministic bar."""
+    ref = np.load(os.path.join(GOLDEN, "images_counter.npz"))[name]
+    h, w, _ = ref.shape
+    opt = RtOptions()
+    opt.jitter_mode, opt.seed = 1, 3
+    sim = H.hostsim_render(ExampleScene(name, w, h), opt)
+    c = H.compare(sim, ref, TOL)
+    assert c["bad_frac"] <= BAD_FRAC[name] + 1e-3, c
+    centre = np.load(os.path.join(GOLDEN, "images.npz"))[name]
+    assert np.abs(sim - centre).max() > 1e-3  # the jitter really moved the samples
+
+
+def test_reference_end_to_end_pixel():
+    sim = H.hostsim_render(ExampleScene("test_world", 11, 11))
+    assert np.abs(sim[5, 5] - np.array([0.38066, 0.47583, 0.2855])).max() <= 1e-5  # camera.rs:353-360
+
+
+@pytest.mark.parametrize("depth", [1, 2, 8])
+def test_depth_limit(depth):
+    # the recursion limit is a parameter of the kernel (world.rs:11 fixes it to 5); the oracle only
+    # knows 5, so other depths are checked for monotone convergence towards it
+    ex = ExampleScene("cover_image", 48, 27)
+    imgs = {}
+    for d in (depth, 5):
+        o = RtOptions()
+        o.max_depth = d
+        imgs[d] = H.hostsim_render(ex, o)
+    ref, _, _ = H.oracle_render("cover_image", 48, 27, threads=4)
+    e_d = np.abs(imgs[depth] - ref).mean()
+    e_5 = np.abs(imgs[5] - ref).mean()
+    assert e_5 <= 1e-6
+    assert (e_d > e_5) if depth < 5 else (e_d < 1e-3)
+
+
+def test_full_resolution_probes_cover_image():
+    """Sparse probes at the config's FULL resolution (3840x2160) against the committed f64 values."""
+    g = np.load(os.path.join(GOLDEN, "probes_cover_image.npz"))
+    w, h, xy, rgb = int(g["width"]), int(g["height"]), g["xy"], g["rgb"]
+    ex = ExampleScene("cover_image", w, h)
+    bad = 0
+    for y in np.unique(xy[:, 1])[:64]:  # one 1-row band per probed row
+        o = RtOptions()
+        o.tile_rows, o.tile_first, o.tile_stride = 1, int(y), h
+        row = H.hostsim_render(ex, o)[0]
+        for k in np.nonzero(xy[:, 1] == y)[0]:
+            bad += int(np.abs(row[xy[k, 0]] - rgb[k]).max() > TOL)
+    assert bad <= 1
