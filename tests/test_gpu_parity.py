@@ -185,7 +185,8 @@ def test_edge_cases():
         o = RtOptions()
         o.max_depth = dep
         imgs[dep], _ = sc.render(ex.camera_desc, o)
-    assert np.abs(imgs[1] - imgs[5]).max() > 1e-3 and np.abs(imgs[8] - imgs[5]).max() < 1e-2
+    d15, d85 = float(np.abs(imgs[1] - imgs[5]).mean()), float(np.abs(imgs[8] - imgs[5]).mean())
+    assert d15 > 1e-3 and d85 < 0.2 * d15, (d15, d85)  # deeper paths carry geometrically less weight
     o = RtOptions()
     o.max_depth = 9
     with pytest.raises(capi.RtError):
