@@ -204,8 +204,10 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved, "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / flopmodel.PEAK_FP32_TFLOPS,
-                "frac_of_unpacked_peak": achieved / flopmodel.PEAK_FP32_UNPACKED_TFLOPS,
+                # HBM bytes per launch: PMC passes are separate runs (scripts/pmc.sh); the committed
+                # summary under profiles/ holds FETCH_SIZE/WRITE_SIZE (≈ the framebuffer write)
                 "traffic": None,
+                "algorithmic_hbm_bytes_per_launch": int(scene.output_rows(ex.camera_desc, opt)) * width * 12,
                 "algorithmic_flop_per_launch": flops, "flop_per_ray_intersection": cost,
                 "kernel": "render_kernel<false>", "kernel_ms": kernel_ms,
             },

@@ -22,9 +22,11 @@ COST_LIGHT_CELL = 50
 COST_LIGHT = 12
 COST_SCHLICK_REFRACT_CHILD = 20 + 25 + 6
 
-# FP32 vector peak of MI355X (MI355X_MICROARCH.md: 157.3 TFLOP/s, packed FMA; 78.6 unpacked)
+# FP32 vector peak of MI355X (MI355X_MICROARCH.md: 157.3 TFLOP/s = 256 CU x 4 SIMD-32 x 2 flop x
+# 2.4 GHz; a wave64 v_fma_f32 issues in 2 cycles, so the peak needs >= 2 waves per SIMD, no packing)
 PEAK_FP32_TFLOPS = 157.3
-PEAK_FP32_UNPACKED_TFLOPS = 78.6
+# wave-instructions per second the chip can issue on its vector pipes (one wave64 VALU op / 2 cycles)
+PEAK_VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 
 
 def flat_ray_cost(scene_desc) -> float:
