@@ -1004,12 +1004,13 @@ inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     return h;
 }
-// jitter = top 8 bits of hash(seed, pixel, node, light, cell, axis) / 255  
+// jitter = one byte of hash(seed, pixel, node, light, cell) / 255: the top byte for the
+// u draw (axis 0, drawn first: light.rs:215), the next byte for the v draw (axis 1)
 inline uint32_t jitter_pixel_key(uint32_t seed, uint32_t pixel) { return fmix32(pixel ^ (seed * 0x9E3779B9u)); }
 inline f64 counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, uint32_t axis) {
-    uint32_t k = (node << 24) | (light << 16) | (cell << 1) | axis;
+    uint32_t k = (node << 24) | (light << 16) | cell;
     uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u);
-    return static_cast<f64>(h >> 24) / 255.0;
+    return static_cast<f64>(axis == 0 ? (h >> 24) : ((h >> 16) & 0xFFu)) / 255.0;
 }
 
 

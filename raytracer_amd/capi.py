@@ -76,7 +76,8 @@ RT_SYMBOLS = [
 
 
 def lib_path() -> str:
-    return os.path.join(_LIBDIR, "librt_amd.so")
+    # RT_AMD_LIB: another BUILD of the same HIP library (kernel timing experiments); never a fallback
+    return os.environ.get("RT_AMD_LIB") or os.path.join(_LIBDIR, "librt_amd.so")
 
 
 _lib: Optional[C.CDLL] = None

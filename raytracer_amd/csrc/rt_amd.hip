@@ -39,13 +39,15 @@
 
 using namespace rtk;
 
+#ifndef RT_EXP
+#define RT_EXP 0  // timing experiments only (scripts/exp_variants.sh): knock out one phase of the shading pass
+#endif
+
 namespace {
 
 struct KScene {
-    const DPrim* prims;
+    const DPrim* recs;  // the traversal stream (rt_math.h)
     const DExtra* extras;
-    const DItem* items;
-    const DNode* nodes;
     const DMaterial* mats;
     const DPattern* pats;
     const DLight* lights;
@@ -69,41 +71,45 @@ __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src
 __device__ __forceinline__ uint32_t shfl_u(uint32_t v, int src) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), src, 64)); }
 __device__ __forceinline__ V3 shfl_v3(V3 v, int src) { return V3{shfl_f(v.x, src), shfl_f(v.y, src), shfl_f(v.z, src)}; }
 
-// Wave-uniform walk over the scene items.  `live` lanes take part; visit(prim index, record, hits)
-// returns whether the lane wants to continue.  Loop control depends only on ballots, so `i` and
-// every record address stay in SGPRs.
+// Wave-uniform walk over the record stream.  `live` lanes take part; visit(index, record) returns
+// whether the lane wants to continue.  Loop control depends only on ballots and on record fields,
+// so the index and the whole record stay in SGPRs (one s_load_dwordx16 per record); the record that
+// follows in the stream is requested before the current one is processed, so its latency hides
+// behind the intersection arithmetic (it is wasted only when a group subtree is jumped).
 template <class Visit>
 __device__ __forceinline__ void traverse(const KScene& sc, const Ray& ray, bool live, Visit&& visit) {
-    uint32_t i = 0;
-    uint32_t skip = 0;  // per lane: sit out items below this index (a group whose box it missed)
     const uint32_t n = sc.n_items;
-    while (i < n) {
+    if (n == 0u) return;
+    uint32_t i = 0;
+    uint32_t skip = 0;  // per lane: sit out records below this index (a group whose box it missed)
+    DPrim rec = sc.recs[0];
+    for (;;) {
         if (!wave_any(live)) break;
-        const DItem it = sc.items[i];
+        const uint32_t seq = i + 1u;
+        const DPrim nxt = sc.recs[seq < n ? seq : i];
         const bool part = live && i >= skip;
-        if (it.ref & kItemNode) {
-            const DNode nd = sc.nodes[it.ref & ~kItemNode];
-            const bool enter = part && node_hit(nd, ray.o, ray.d);
-            if (part && !enter) skip = it.next;
-            i = wave_any(enter) ? i + 1 : it.next;
-        } else {
-            if (part) {
-                const DPrim p = sc.prims[it.ref];
-                Hits h;
-                intersect_prim(p, sc.extras, ray, ray.self == it.ref, h);
-                live = visit(it.ref, p, h);
-            }
-            i = i + 1;
+        uint32_t to = seq;
+        if (rec.type == REC_NODE) {
+            const bool enter = part && node_hit(rec, ray.o, ray.d);
+            if (part && !enter) skip = rec.material;
+            if (!wave_any(enter)) to = rec.material;
+        } else if (part) {
+            live = visit(i, rec);
         }
+        if (to >= n) break;
+        if (to == seq) rec = nxt;
+        else rec = sc.recs[to];
+        i = to;
     }
 }
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live) {
     bool occ = false;
-    traverse(sc, ray, live, [&](uint32_t, const DPrim&, const Hits& h) {
-        for (int k = 0; k < 4; ++k)
-            if (k < h.n && h.t[k] > 0.0f && h.t[k] < dist) occ = true;
+    traverse(sc, ray, live, [&](uint32_t prim, const DPrim& p) {
+        intersect_prim(p, sc.extras, ray, ray.self == prim, [&](int, float t, float, float) {
+            if (t > 0.0f && t < dist) occ = true;
+        });
         return !occ;
     });
     return occ;
@@ -117,7 +123,10 @@ struct StackEntry {
 __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - static_cast<uint32_t>(__clz(static_cast<int>(node + 1u))); }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(const KParams P) {
+// 4 waves per SIMD (<= 128 VGPRs): the kernel waits on scalar loads, cross-lane traffic and
+// transcendental latency, and measured 35 % faster at 4 waves/SIMD with a few spilled registers than
+// at 2 without (5 and more waves spill too much; profiles/r01_occupancy_sweep.txt).
+__global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave >= P.n_tiles) return;
@@ -154,14 +163,10 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
         // ---------------------------------------------------------------- trace (world.rs:24-41)
         uint32_t hit_prim = kNoPrim;
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
-        traverse(sc, cur, active, [&](uint32_t prim, const DPrim&, const Hits& h) {
-            for (int k = 0; k < 4; ++k)
-                if (k < h.n && closer_hit(h.t[k], hit_t)) {  // intersection.rs:105-120
-                    hit_t = h.t[k];
-                    hit_prim = prim;
-                    hit_u = h.u;
-                    hit_v = h.v;
-                }
+        traverse(sc, cur, active, [&](uint32_t prim, const DPrim& p) {
+            intersect_prim(p, sc.extras, cur, cur.self == prim, [&](int, float t, float u, float v) {
+                if (closer_hit(t, hit_t)) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;  // intersection.rs:105-120
+            });
             return true;
         });
         const bool has_hit = active && hit_prim != kNoPrim;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
         DMaterial m{};
         V3 over = v3(0.0f, 0.0f, 0.0f), pc = v3(0.0f, 0.0f, 0.0f);
         if (has_hit) {
-            const DPrim p = sc.prims[hit_prim];
+            const DPrim p = sc.recs[hit_prim];
             m = sc.mats[p.material];
             h = prepare_hit(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
             over = h.p + h.n * kEps;
@@ -190,10 +195,12 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
                 // light.rs:182-188 + material.rs:138-159 with a single cell
                 const V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
                 const V3 tl = lp - over;
-                const float dist = sqrtf(dot(tl, tl));
-                const bool cast = has_hit && !(fabsf(dist) <= kEps);
+                const float dist2 = dot(tl, tl);
+                const float inv_dist = rsq_f(dist2);
+                const float dist = dist2 * inv_dist;
+                const bool cast = has_hit && dist2 > kEps * kEps;
                 Ray sr;
-                sr.o = over, sr.d = tl * (1.0f / dist), sr.self = hit_prim, sr.q = h.q, sr.dq = h.dq;
+                sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = h.q, sr.dq = h.dq;
                 const bool occ = occluded(sc, sr, dist, cast);
                 lit = occ ? 0.0f : 1.0f;
                 if (has_hit) phong_cell(lp, over, h.n, h.eye, m.shininess, sum_d, sum_s);
@@ -208,6 +215,9 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
                 const uint32_t chunks = (cells + 63u) >> 6;
                 const uint32_t slot = lane >> glog, sub = lane & (g - 1u);
                 const unsigned long long gmask = g == 64u ? ~0ull : ((1ull << g) - 1ull);
+                // this lane's cell of chunk 0 and its centre do not depend on the shading point
+                const uint32_t cv0 = sub / l.usteps, cu0 = sub - cv0 * l.usteps;
+                const V3 centre0 = point_on_light(l, cu0, cv0, 0.5f, 0.5f);
                 unsigned long long need = __ballot(has_hit);
                 while (need) {
                     int owner = 0;
@@ -235,27 +245,44 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
                     for (uint32_t ch = 0; ch < chunks; ++ch) {
                         const uint32_t cell = ch * 64u + sub;
                         const bool con = lane_on && cell < cells;
-                        const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
-                        float ju = 0.5f, jv = 0.5f;
-                        if (P.jitter_mode == RT_JITTER_COUNTER) {
-                            ju = counter_jitter(o_key, o_node, li, cell, 0u);  // first draw goes to u (light.rs:215)
-                            jv = counter_jitter(o_key, o_node, li, cell, 1u);
+                        uint32_t cv = cv0, cu = cu0;
+                        V3 centre = centre0;
+                        if (ch != 0u) {  // lights with more than 64 cells only
+                            cv = cell / l.usteps, cu = cell - cv * l.usteps;
+                            centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
                         }
-                        const V3 lp = point_on_light(l, cu, cv, ju, jv);
+                        V3 lp = centre;
+                        if (P.jitter_mode == RT_JITTER_COUNTER) {
+                            float ju, jv;
+                            counter_jitter(o_key, o_node, li, cell, ju, jv);
+                            lp = point_on_light(l, cu, cv, ju, jv);
+                        }
                         const V3 tl = lp - o_over;
-                        const float dist = sqrtf(dot(tl, tl));
-                        const bool cast = con && !(fabsf(dist) <= kEps);
-                        sr.d = tl * (1.0f / dist);
+                        const float dist2 = dot(tl, tl);
+                        const float inv_dist = rsq_f(dist2);
+                        const float dist = dist2 * inv_dist;
+                        const bool cast = con && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
+                        sr.d = tl * inv_dist;
+#if RT_EXP & 4
+                        const bool occ = cast && dist > 1e30f;
+#else
                         const bool occ = occluded(sc, sr, dist, cast);
+#endif
                         const unsigned long long b = __ballot(con && !occ);
                         float ldn = 0.0f, spec = 0.0f;
-                        if (con) phong_cell(point_on_light(l, cu, cv, 0.5f, 0.5f), o_over, o_n, o_eye, o_shin, ldn, spec);
+#if !(RT_EXP & 2)
+                        if (con) phong_cell(centre, o_over, o_n, o_eye, o_shin, ldn, spec);
+#endif
+                        const int lead = static_cast<int>(my_slot << glog);
+#if RT_EXP & 1
+                        const float rd = ldn, rs = spec;
+#else
                         for (uint32_t s = 1; s < g; s <<= 1) {  // butterfly inside the slot's lane group
                             ldn += __shfl_xor(ldn, static_cast<int>(s), 64);
                             spec += __shfl_xor(spec, static_cast<int>(s), 64);
                         }
-                        const int lead = static_cast<int>(my_slot << glog);
                         const float rd = shfl_f(ldn, lead), rs = shfl_f(spec, lead);
+#endif
                         if (owner_now) {
                             my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
                             my_d += rd;
@@ -284,34 +311,16 @@ __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
         float n1 = 1.0f, n2 = 1.0f;
         const bool need_n = has_hit && depth > 0u && m.transparency > 0.0f;
         if (wave_any(need_n)) {
-            // intersection.rs:71-103 without the sorted list (see DESIGN.md "n1/n2")
-            float best_t = -INFINITY, best_ior = 1.0f, hit_last = -INFINITY;
-            bool have_best = false, hit_in = false;
-            traverse(sc, cur, need_n, [&](uint32_t prim, const DPrim& p, const Hits& hh) {
-                const bool is_hit_prim = prim == hit_prim;
-                int skipk = -1;
-                float bd = INFINITY;
-                for (int k = 0; k < 4; ++k)
-                    if (is_hit_prim && k < hh.n && fabsf(hh.t[k] - hit_t) < bd) bd = fabsf(hh.t[k] - hit_t), skipk = k;
-                int cnt = 0;
-                float last = -INFINITY;
-                for (int k = 0; k < 4; ++k)
-                    if (k < hh.n && k != skipk && precedes_hit(hh.t[k], hit_t, prim, hit_prim)) ++cnt, last = fmaxf(last, hh.t[k]);
-                if (cnt & 1) {
-                    if (is_hit_prim) hit_in = true, hit_last = last;
-                    else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = p.ior;
-                }
+            ContainerScan cs;  // intersection.rs:71-103 without the sorted list
+            traverse(sc, cur, need_n, [&](uint32_t prim, const DPrim& p) {
+                Hits hh;
+                hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
+                intersect_prim(p, sc.extras, cur, cur.self == prim, [&](int slot, float t, float, float) { hh.t[slot] = t; });
+                cs.add(hh, prim, p.ior, hit_prim, hit_t);
                 return true;
             });
             if (need_n) {
-                const float excl = have_best ? best_ior : 1.0f;
-                if (hit_in) {
-                    n1 = (!have_best || hit_last > best_t) ? m.ior : best_ior;
-                    n2 = excl;
-                } else {
-                    n1 = excl;
-                    n2 = m.ior;
-                }
+                cs.finish(m.ior, n1, n2);
                 if (STATS) c_container++;
             }
         }
@@ -548,14 +557,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     rt_scene* s = new (std::nothrow) rt_scene;
     if (!s) return fail(RT_ERR_CAPACITY, "out of host memory");
     s->device = device;
-    rc = upload(ps.prims, &s->k.prims, s->owned);
+    rc = upload(ps.recs, &s->k.recs, s->owned);
     if (rc == RT_OK) rc = upload(ps.extras, &s->k.extras, s->owned);
-    if (rc == RT_OK) rc = upload(ps.items, &s->k.items, s->owned);
-    if (rc == RT_OK) rc = upload(ps.nodes, &s->k.nodes, s->owned);
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
     if (rc == RT_OK) rc = upload(ps.pats, &s->k.pats, s->owned);
     if (rc == RT_OK) rc = upload(ps.lights, &s->k.lights, s->owned);
-    if (ps.prims.empty()) s->k.n_items = 0;
     s->k.n_items = ps.n_items;
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {

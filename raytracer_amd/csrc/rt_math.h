@@ -29,22 +29,36 @@ namespace rtk {
 
 constexpr float kEps = 1e-5f;  // float.rs:3
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32).  `a / b` and sqrtf()
+// would expand to the ~10-instruction correctly-rounded sequences; nothing on this path needs the
+// last ulp (every ulp-sensitive step is formulated so that it does not cancel, see the header), and
+// x * rcp(0) keeps the IEEE +-inf / NaN outcomes the slab tests rely on (cube.rs:83).
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_HD float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
+RT_HD float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
+RT_HD float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32; gates only, never a result
+#else
+RT_HD float fast_log2(float x) { return log2f(x); }
+RT_HD float rcp_f(float x) { return 1.0f / x; }
+RT_HD float sqrt_f(float x) { return sqrtf(x); }
+RT_HD float rsq_f(float x) { return 1.0f / sqrtf(x); }
+#endif
+RT_HD float div_f(float a, float b) { return a * rcp_f(b); }
+
 // Device-side records (built by rt_scene_create from rt_scene_desc; see DESIGN.md "HBM layout").
+// The scene is ONE stream of 64-byte records in traversal order (world.objects order, groups in
+// depth-first pre-order): record i is a primitive, or a group node whose subtree is the records
+// (i, next).  A primitive is identified everywhere on the device by its position in the stream.
 struct DPrim {  // 64 B — one s_load_dwordx16 when the index is wave-uniform
-    float inv[12];
-    uint32_t type;
-    uint32_t material;
-    float ior;  // copy of the material's index_of_refraction (container pass)
-    uint32_t extra;
+    float inv[12];      // primitive: transform_inverse rows.  node: box min = inv[0..2], max = inv[3..5]
+    uint32_t type;      // PRIM_* or REC_NODE
+    uint32_t material;  // primitive: material index.  node: `next`, the record after its subtree
+    float ior;          // copy of the material's index_of_refraction (container pass)
+    uint32_t extra;     // index into DExtra (cylinder, triangles)
 };
 struct DExtra {  // 128 B: cylinder {min,max,closed}; triangle {v0,e0,e1,normal,n0,n1,n2}
     float f[32];
-};
-struct DItem {
-    uint32_t ref, next;
-};
-struct DNode {  // 32 B
-    float mn[3], pad0, mx[3], pad1;
 };
 struct DMaterial {  // 32 B
     float ambient, diffuse, specular, shininess, ior, reflectivity, transparency;
@@ -73,7 +87,8 @@ struct DCamera {
     float inv[12];
 };
 
-enum : uint32_t { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_CUBE = 2, PRIM_CYLINDER = 3, PRIM_TRIANGLE = 4, PRIM_SMOOTH = 5 };
+enum : uint32_t { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_CUBE = 2, PRIM_CYLINDER = 3, PRIM_TRIANGLE = 4, PRIM_SMOOTH = 5,
+                  REC_NODE = 6 };
 enum : uint32_t { PAT_SOLID = 0, PAT_STRIPE = 1, PAT_GRADIENT = 2, PAT_RING = 3, PAT_CHECKER = 4 };
 constexpr uint32_t kItemNode = 0x80000000u;
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
@@ -103,8 +118,7 @@ RT_HD V3 cross_exact(V3 a, V3 b) {
 }
 RT_HD V3 madd(V3 d, float t, V3 o) { return V3{fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)}; }  // o + d*t
 RT_HD V3 normalize(V3 a) {
-    float inv = 1.0f / sqrtf(dot(a, a));
-    return a * inv;
+    return a * rsq_f(dot(a, a));
 }
 
 // 3x4 affine (rows) applied to a point / a vector / transposed-linear applied to a normal.
@@ -164,14 +178,12 @@ struct Ray {
     V3 dq;          // object-space offset: origin_obj = q + dq  (= +-1e-5 * inv_linear * world normal)
 };
 
-// Up to four parametric hits of one primitive (cylinder: 2 wall + 2 caps), plus triangle (u, v).
-// `n` is the number of slots to look at and depends only on the primitive TYPE (so it is
-// wave-uniform); an absent intersection is NaN, which fails every ordered comparison the visitors
-// make (t > 0, t < best, t < t_hit).  Slots are only ever indexed by constants: they stay in VGPRs.
-struct Hits {
-    int n;
+// The intersections of one primitive are handed to an `emit(slot, t, u, v)` functor as they are
+// found: slot is a compile-time constant at every call site (0/1 = the two roots or slab
+// distances, 2/3 = cylinder caps), so a visitor that stores them indexes registers, and a visitor
+// that only wants the nearest hit or "any hit before the light" keeps no list at all.
+struct Hits {  // slot store used by the container pass (intersection.rs:71-103); absent = NaN
     float t[4];
-    float u, v;
 };
 #define RT_NOHIT __builtin_nanf("")
 
@@ -183,56 +195,55 @@ struct Hits {
 // l -+ half*d (prepare_hit), whose error is ~1e-7 object units however far away the ray started;
 // o + t*d would carry the full rounding error of t (~1e-7 * distance) into the normal.
 RT_HD bool sphere_foot(V3 o, V3 d, float a, float& tc, V3& l, float& half) {
-    float inv_a = 1.0f / a;
+    float inv_a = rcp_f(a);
     float tc0 = -dot(d, o) * inv_a;
     V3 l0 = madd(d, tc0, o);
     float e = dot(l0, d) * inv_a;
     tc = tc0 - e;
     l = madd(d, -e, l0);
     float m = 1.0f - dot(l, l);
-    half = sqrtf(fmaxf(m, 0.0f) * inv_a);
+    half = sqrt_f(fmaxf(m, 0.0f) * inv_a);
     return !(m < 0.0f);
 }
 
-// sphere.rs:38-72.  a = d.d, h = d.o (= b/2), c = o.o - 1.  Always two roots when it hits.
-RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Hits& r) {
-    r.n = 2;
-    r.t[0] = RT_NOHIT, r.t[1] = RT_NOHIT;
-    float a = dot(d, d);
-    if (self) {
-        // |q| == 1 exactly by construction, so c = |q + dq|^2 - 1 = 2 q.dq + dq.dq without cancellation
-        V3 os = q + dq;
-        float h = dot(d, os);
-        float c = fmaf(2.0f, dot(q, dq), dot(dq, dq));
-        float disc = fmaf(h, h, -(a * c));
-        if (disc < 0.0f) return;
-        float sq = sqrtf(disc);
-        float qq = -(h + copysignf(sq, h));
-        float ta = qq / a;
-        float tb = (qq != 0.0f) ? c / qq : ta;
-        r.t[0] = fminf(ta, tb);
-        r.t[1] = fmaxf(ta, tb);
-        return;
-    }
-    float tc, half;
-    V3 l;
-    if (!sphere_foot(o, d, a, tc, l, half)) return;  // discriminant < 0  (sphere.rs:51)
-    r.t[0] = tc - half;
-    r.t[1] = tc + half;
+// Roots of a t^2 + 2 h t + c = 0 for a ray that STARTS on the quadric (c ~ 1e-5, no cancellation
+// left in it): Vieta for the near root.  false = discriminant < 0.
+RT_HD bool on_surface_roots(float a, float h, float c, float& t0, float& t1) {
+    float disc = fmaf(h, h, -(a * c));
+    if (disc < 0.0f) return false;
+    float sq = sqrt_f(disc);
+    float qq = -(h + copysignf(sq, h));
+    float ta = div_f(qq, a);
+    float tb = (qq != 0.0f) ? div_f(c, qq) : ta;
+    t0 = fminf(ta, tb), t1 = fmaxf(ta, tb);
+    return true;
 }
 
-// plane.rs:39-51 — only the y row of the inverse is needed.
-RT_HD void isect_plane(float oy, float dy, Hits& r) {
-    r.n = 1;
-    r.t[0] = (fabsf(dy) <= kEps) ? RT_NOHIT : -oy / dy;
+// sphere.rs:38-72.  a = d.d, h = d.o (= b/2), c = o.o - 1.  Always two roots when it hits.
+template <class Emit>
+RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit) {
+    float a = dot(d, d);
+    float t0, t1;
+    if (self) {
+        // |q| == 1 exactly by construction, so c = |q + dq|^2 - 1 = 2 q.dq + dq.dq without cancellation
+        if (!on_surface_roots(a, dot(d, q + dq), fmaf(2.0f, dot(q, dq), dot(dq, dq)), t0, t1)) return;
+    } else {
+        float tc, half;
+        V3 l;
+        if (!sphere_foot(o, d, a, tc, l, half)) return;  // discriminant < 0  (sphere.rs:51)
+        t0 = tc - half, t1 = tc + half;
+    }
+    emit(0, t0, 0.0f, 0.0f);
+    emit(1, t1, 0.0f, 0.0f);
 }
 
 // cube.rs:39-122 (the same slab code serves Group boxes: bounding_box.rs:81-84).
 // num_lo / num_hi are (min - origin) and (max - origin) per axis.
 RT_HD void slab_axis(float num_lo, float num_hi, float d, float& tmin, float& tmax) {
     // cube.rs:83: `ge(|d|, EPSILON)` is approximate and therefore true for every finite d, so the
-    // IEEE division below (x/0 = +-inf, 0/0 = NaN) is what the reference always executes.
-    float a = num_lo / d, b = num_hi / d;
+    // IEEE division (x/0 = +-inf, 0/0 = NaN) is what the reference always executes.
+    float inv_d = rcp_f(d);
+    float a = num_lo * inv_d, b = num_hi * inv_d;
     bool sw = a > b;
     tmin = sw ? b : a;
     tmax = sw ? a : b;
@@ -245,7 +256,8 @@ RT_HD void isect_box(V3 num_lo, V3 num_hi, V3 d, float& tmin, float& tmax) {
     tmin = max_by3(x0, y0, z0);
     tmax = min_by3(x1, y1, z1);
 }
-RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Hits& r) {
+template <class Emit>
+RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit) {
     V3 lo, hi;
     if (self) {  // the snapped coordinate of q is exactly +-1, so (bound - q) is exactly 0 or +-2
         lo = (v3(-1.0f, -1.0f, -1.0f) - q) - dq;
@@ -256,36 +268,28 @@ RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Hits& r) {
     }
     float tmin, tmax;
     isect_box(lo, hi, d, tmin, tmax);
-    const bool miss = tmin > tmax;  // cube.rs:104
-    r.n = 2;
-    r.t[0] = miss ? RT_NOHIT : tmin;
-    r.t[1] = miss ? RT_NOHIT : tmax;
+    if (tmin > tmax) return;  // cube.rs:104
+    emit(0, tmin, 0.0f, 0.0f);
+    emit(1, tmax, 0.0f, 0.0f);
 }
 
 // cylinder.rs:126-225
 RT_HD bool cyl_check_cap(float ox, float oz, float dx, float dz, float t) {
     float x = fmaf(t, dx, ox), z = fmaf(t, dz, oz);
     float rr = fmaf(x, x, z * z);
-    return approx(rr, 1.0f) || rr < 1.0f;  // le(x^2 + z^2, 1)
+    return rr <= 1.0f + kEps;  // le(x^2 + z^2, 1)
 }
-RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float ymax, bool closed, Hits& r) {
-    r.n = 4;
-    r.t[0] = RT_NOHIT, r.t[1] = RT_NOHIT, r.t[2] = RT_NOHIT, r.t[3] = RT_NOHIT;
+template <class Emit>
+RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float ymax, bool closed, Emit&& emit) {
     V3 os = self ? q + dq : o;
     float a = fmaf(d.x, d.x, d.z * d.z);
     if (!approx(a, 0.0f)) {
         float t0, t1;
         if (self && fabsf(fmaf(q.x, q.x, q.z * q.z) - 1.0f) < 1e-3f) {
-            // origin on the wall: q_x^2 + q_z^2 == 1 exactly, c has no cancellation; Vieta for the near root
-            float h = fmaf(os.x, d.x, os.z * d.z);  // b / 2
+            // origin on the wall: q_x^2 + q_z^2 == 1 exactly, c has no cancellation
+            float h = fmaf(os.x, d.x, os.z * d.z);  // b/2
             float c = fmaf(2.0f, fmaf(q.x, dq.x, q.z * dq.z), fmaf(dq.x, dq.x, dq.z * dq.z));
-            float disc = fmaf(h, h, -(a * c));
-            if (disc < 0.0f) return;  // cylinder.rs:140-142 returns WITHOUT testing the caps
-            float sq = sqrtf(disc);
-            float qq = -(h + copysignf(sq, h));
-            float ta = qq / a;
-            float tb = (qq != 0.0f) ? c / qq : ta;
-            t0 = fminf(ta, tb), t1 = fmaxf(ta, tb);
+            if (!on_surface_roots(a, h, c, t0, t1)) return;  // cylinder.rs:140-142 returns WITHOUT testing the caps
         } else {
             // the sphere_foot construction in the xz plane
             float tc, half;
@@ -294,9 +298,9 @@ RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float 
             t0 = tc - half, t1 = tc + half;
         }
         float y0 = fmaf(t0, d.y, os.y);
-        if (ymin < y0 && y0 < ymax) r.t[0] = t0;
+        if (ymin < y0 && y0 < ymax) emit(0, t0, 0.0f, 0.0f);
         float y1 = fmaf(t1, d.y, os.y);
-        if (ymin < y1 && y1 < ymax) r.t[1] = t1;
+        if (ymin < y1 && y1 < ymax) emit(1, t1, 0.0f, 0.0f);
     }
     if (!closed || approx(d.y, 0.0f)) return;  // cylinder.rs:192
     float nlo, nhi;
@@ -307,62 +311,60 @@ RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float 
         nlo = ymin - o.y;
         nhi = ymax - o.y;
     }
-    float t = nlo / d.y;
-    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) r.t[2] = t;
-    t = nhi / d.y;
-    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) r.t[3] = t;
+    float inv_dy = rcp_f(d.y);
+    float t = nlo * inv_dy;
+    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) emit(2, t, 0.0f, 0.0f);
+    t = nhi * inv_dy;
+    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) emit(3, t, 0.0f, 0.0f);
 }
 
 // triangle.rs:104-133 (Moller-Trumbore); e = {v0, e0, e1}
-RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Hits& r) {
-    r.n = 1;
-    r.t[0] = RT_NOHIT;
+template <class Emit>
+RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Emit&& emit) {
     V3 dir_cross_e1 = cross(d, e1);
     float det = dot(e0, dir_cross_e1);
     if (fabsf(det) <= kEps) return;
-    float f = 1.0f / det;
+    float f = rcp_f(det);
     V3 p0 = o - v0;
     float u = f * dot(p0, dir_cross_e1);
     if (!(u >= 0.0f && u <= 1.0f)) return;
     V3 oxe0 = cross(p0, e0);
     float v = f * dot(d, oxe0);
     if (v < 0.0f || (u + v) > 1.0f) return;
-    r.t[0] = f * dot(e1, oxe0);
-    r.u = u;
-    r.v = v;
+    emit(0, f * dot(e1, oxe0), u, v);
 }
 
 // Dispatch: world ray -> object space (shape.rs:79-81, ray.rs:17-22) -> primitive test.
-RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Hits& r) {
-    r.u = 0.0f, r.v = 0.0f;
+template <class Emit>
+RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Emit&& emit) {
     switch (p.type) {
-        case PRIM_PLANE: {
+        case PRIM_PLANE: {  // plane.rs:39-51 — only the y row of the inverse is needed
             float oy = self ? ray.dq.y : fmaf(p.inv[4], ray.o.x, fmaf(p.inv[5], ray.o.y, fmaf(p.inv[6], ray.o.z, p.inv[7])));
             float dy = fmaf(p.inv[4], ray.d.x, fmaf(p.inv[5], ray.d.y, p.inv[6] * ray.d.z));
-            isect_plane(oy, dy, r);
+            if (!(fabsf(dy) <= kEps)) emit(0, div_f(-oy, dy), 0.0f, 0.0f);
             break;
         }
         case PRIM_SPHERE: {
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
-            isect_sphere(o, d, self, ray.q, ray.dq, r);
+            isect_sphere(o, d, self, ray.q, ray.dq, emit);
             break;
         }
         case PRIM_CUBE: {
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
-            isect_cube(o, d, self, ray.q, ray.dq, r);
+            isect_cube(o, d, self, ray.q, ray.dq, emit);
             break;
         }
         case PRIM_CYLINDER: {
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             const float* e = extras[p.extra].f;
-            isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, r);
+            isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, emit);
             break;
         }
         default: {  // PRIM_TRIANGLE, PRIM_SMOOTH
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             if (self) o = ray.q + ray.dq;
             const float* e = extras[p.extra].f;
-            isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), r);
+            isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), emit);
             break;
         }
     }
@@ -370,12 +372,49 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
 
 // Group box test on the WORLD ray (group.rs:107, bounding_box.rs:81-84): hit iff tmin < tmax on
 // the whole line.  The device boxes are widened by a few ulps at upload so FP32 rounding cannot
-// cull a child the f64 test would have entered.
-RT_HD bool node_hit(const DNode& n, V3 o, V3 d) {
+// cull a child the f64 test would have entered.  A node record keeps min in inv[0..2], max in
+// inv[3..5] and its skip link in `material`.
+RT_HD bool node_hit(const DPrim& n, V3 o, V3 d) {
     float tmin, tmax;
-    isect_box(v3(n.mn[0], n.mn[1], n.mn[2]) - o, v3(n.mx[0], n.mx[1], n.mx[2]) - o, d, tmin, tmax);
+    isect_box(v3(n.inv[0], n.inv[1], n.inv[2]) - o, v3(n.inv[3], n.inv[4], n.inv[5]) - o, d, tmin, tmax);
     return tmin < tmax;
 }
+
+// intersection.rs:71-103 without the sorted list.  The reference walks the sorted intersections up
+// to the hit, toggling each object in a container list; n1 is the material of the list's last entry
+// before the hit toggles, n2 after.  Equivalent, per primitive: it is in the list at the hit iff an
+// ODD number of its intersections precede the hit, and the list's last entry is the contained
+// primitive whose latest preceding crossing has the largest t.
+struct ContainerScan {
+    float best_t = -INFINITY, best_ior = 1.0f, hit_last = -INFINITY;
+    bool have_best = false, hit_in = false;
+
+    RT_HD void add(const Hits& h, uint32_t prim, float ior, uint32_t hit_prim, float t_hit) {
+        const bool is_hit_prim = prim == hit_prim;
+        int skipk = -1;  // the hit itself = the hit primitive's intersection closest to t_hit
+        float bd = INFINITY;
+        for (int k = 0; k < 4; ++k)
+            if (is_hit_prim && fabsf(h.t[k] - t_hit) < bd) bd = fabsf(h.t[k] - t_hit), skipk = k;
+        int cnt = 0;
+        float last = -INFINITY;
+        for (int k = 0; k < 4; ++k)
+            if (k != skipk && h.t[k] == h.t[k] && precedes_hit(h.t[k], t_hit, prim, hit_prim)) ++cnt, last = fmaxf(last, h.t[k]);
+        if (cnt & 1) {
+            if (is_hit_prim) hit_in = true, hit_last = last;
+            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = ior;
+        }
+    }
+    RT_HD void finish(float hit_ior, float& n1, float& n2) const {
+        const float excl = have_best ? best_ior : 1.0f;
+        if (hit_in) {
+            n1 = (!have_best || hit_last > best_t) ? hit_ior : best_ior;
+            n2 = excl;
+        } else {
+            n1 = excl;
+            n2 = hit_ior;
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Hit preparation: intersection.rs:40-69 + shape.rs:83-96,118-137 + per-shape normal_at.
@@ -438,7 +477,7 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
                 V3 d2 = v3(d.x, 0.0f, d.z);
                 sphere_foot(v3(o.x, 0.0f, o.z), d2, dot(d2, d2), tc, l, half);
                 V3 w = madd(d2, (t < tc) ? -half : half, l);
-                float s = 1.0f / sqrtf(fmaf(w.x, w.x, w.z * w.z));
+                float s = rsq_f(fmaf(w.x, w.x, w.z * w.z));
                 q.x = w.x * s, q.z = w.z * s;
                 nobj = v3(q.x, 0.0f, q.z);
             }
@@ -469,16 +508,22 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
 
 // ---------------------------------------------------------------------------------------------
 // pattern.rs:58-96, evaluated at the object-space over_point (q + dq)
+// `|f % 2| <= 1e-5` (pattern.rs:74,82,89) for an integer-valued f: f/2 has no fractional part.  Exact
+// (halving and truncation do not round); every float >= 2^24 is even; inf/NaN give false like fmod.
+RT_HD bool is_even(float f) {
+    float h = 0.5f * f;
+    return h - truncf(h) == 0.0f;
+}
 RT_HD V3 pattern_color(const DPattern& pat, V3 obj_point) {
     V3 a = v3(pat.a[0], pat.a[1], pat.a[2]);
     if (pat.type == PAT_SOLID) return a;
     V3 b = v3(pat.b[0], pat.b[1], pat.b[2]);
     V3 pp = xform_point(pat.inv, obj_point);
     switch (pat.type) {
-        case PAT_STRIPE: return fabsf(fmodf(floorf(pp.x), 2.0f)) <= kEps ? a : b;
+        case PAT_STRIPE: return is_even(floorf(pp.x)) ? a : b;
         case PAT_GRADIENT: return a + (b - a) * (pp.x - floorf(pp.x));
-        case PAT_RING: return fabsf(fmodf(floorf(sqrtf(fmaf(pp.x, pp.x, pp.z * pp.z))), 2.0f)) <= kEps ? a : b;
-        default: return fabsf(fmodf(floorf(pp.x) + floorf(pp.y) + floorf(pp.z), 2.0f)) <= kEps ? a : b;
+        case PAT_RING: return is_even(floorf(sqrtf(fmaf(pp.x, pp.x, pp.z * pp.z)))) ? a : b;
+        default: return is_even(floorf(pp.x) + floorf(pp.y) + floorf(pp.z)) ? a : b;
     }
 }
 
@@ -486,26 +531,30 @@ RT_HD V3 pattern_color(const DPattern& pat, V3 obj_point) {
 // already gated (0 when the reference skips them).
 RT_HD void phong_cell(V3 cell, V3 point, V3 n, V3 eye, float shininess, float& ldn_out, float& spec_out) {
     V3 lv = cell - point;
-    float len = sqrtf(dot(lv, lv));
-    V3 lightv = (fabsf(len) <= kEps) ? v3(0.0f, 0.0f, 0.0f) : lv * (1.0f / len);  // normalize().unwrap_or(0)
+    float len2 = dot(lv, lv);
+    V3 lightv = (len2 <= kEps * kEps) ? v3(0.0f, 0.0f, 0.0f) : lv * rsq_f(len2);  // normalize().unwrap_or(0)
     float ldn = dot(lightv, n);
     ldn_out = 0.0f;
     spec_out = 0.0f;
-    if (approx(ldn, 0.0f) || ldn > 0.0f) {  // float::ge(light_dot_normal, 0.0)
+    if (ldn >= -kEps) {  // float::ge(light_dot_normal, 0.0)
         ldn_out = ldn;
         V3 ml = neg(lightv);
         V3 rv = ml - n * 2.0f * dot(ml, n);  // (-lightv).reflect(normalv)
         float rde = dot(rv, eye);
-        if (rde > 0.0f) {
-            // factor = (reflect . eye)^shininess (material.rs:150-153).  x^200 turns the 1e-7 absolute
-            // rounding error of an FP32 dot product of two unit vectors into 2e-5 RELATIVE error on
-            // highlights whose value exceeds 1, so cos(theta) is taken from the cross product
-            // instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full relative accuracy in
-            // (1 - cos), and the power is exp(shininess/2 * log1p(-sin^2)).
+        // factor = (reflect . eye)^shininess (material.rs:150-153).  Outside the highlight the factor
+        // is below 2^-36 and is dropped (1e-11 of a colour unit) — most cells of most shading points,
+        // so the wave usually skips the power altogether.
+        if (rde > 0.0f && shininess * fast_log2(rde) > -36.0f) {
+            // x^200 turns the 1e-7 absolute rounding error of an FP32 dot product of two unit
+            // vectors into 2e-5 RELATIVE error on highlights whose value exceeds 1, so cos(theta) is
+            // taken from the cross product instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full
+            // relative accuracy in (1 - cos), and the power is exp(shininess/2 * log1p(-sin^2)).
             V3 cx = cross_exact(rv, eye);
-            float sin2 = dot(cx, cx) / (dot(rv, rv) * dot(eye, eye));
-            sin2 = fminf(sin2, 1.0f);
-            spec_out = (sin2 < 0.25f) ? expf(0.5f * shininess * log1pf(-sin2)) : powf(rde, shininess);
+            float sin2 = fminf(div_f(dot(cx, cx), dot(rv, rv) * dot(eye, eye)), 1.0f);
+            if (sin2 < 0.25f)
+                spec_out = expf(0.5f * shininess * log1pf(-sin2));
+            else
+                spec_out = powf(rde, shininess);
         }
     }
 }
@@ -514,12 +563,12 @@ RT_HD void phong_cell(V3 cell, V3 point, V3 n, V3 eye, float shininess, float& l
 RT_HD float schlick(V3 eye, V3 n, float n1, float n2) {
     float c = dot(eye, n);
     if (n1 > n2) {
-        float r = n1 / n2;
+        float r = div_f(n1, n2);
         float sin2_t = r * r * (1.0f - c * c);
         if (sin2_t > 1.0f) return 1.0f;
-        c = sqrtf(1.0f - sin2_t);
+        c = sqrt_f(1.0f - sin2_t);
     }
-    float r0 = (n1 - n2) / (n1 + n2);
+    float r0 = div_f(n1 - n2, n1 + n2);
     r0 *= r0;
     float k = 1.0f - c;
     float k2 = k * k;
@@ -528,11 +577,11 @@ RT_HD float schlick(V3 eye, V3 n, float n1, float n2) {
 
 // world.rs:113-125: returns false under total internal reflection
 RT_HD bool refract_dir(V3 eye, V3 n, float n1, float n2, V3& dir) {
-    float r = n1 / n2;
+    float r = div_f(n1, n2);
     float cos_i = dot(eye, n);
     float sin2_t = r * r * (1.0f - cos_i * cos_i);
     if (sin2_t > 1.0f) return false;
-    float cos_t = sqrtf(1.0f - sin2_t);
+    float cos_t = sqrt_f(1.0f - sin2_t);
     dir = n * (r * cos_i - cos_t) - eye * r;
     return true;
 }
@@ -556,10 +605,12 @@ RT_HD uint32_t fmix32(uint32_t h) {
     return h;
 }
 RT_HD uint32_t jitter_pixel_key(uint32_t seed, uint32_t pixel) { return fmix32(pixel ^ (seed * 0x9E3779B9u)); }
-RT_HD float counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, uint32_t axis) {
-    uint32_t k = (node << 24) | (light << 16) | (cell << 1) | axis;
+// One hash per (pixel, path node, light, cell); the u draw is its top byte, the v draw the next one.
+RT_HD void counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, float& ju, float& jv) {
+    uint32_t k = (node << 24) | (light << 16) | cell;
     uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u);
-    return static_cast<float>(h >> 24) / 255.0f;
+    ju = static_cast<float>(h >> 24) * (1.0f / 255.0f);
+    jv = static_cast<float>((h >> 16) & 0xFFu) * (1.0f / 255.0f);
 }
 
 // light.rs:211-216

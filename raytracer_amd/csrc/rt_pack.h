@@ -15,10 +15,8 @@
 namespace rtk {
 
 struct PackedScene {
-    std::vector<DPrim> prims;
+    std::vector<DPrim> recs;  // the traversal stream: one record per item, in item order
     std::vector<DExtra> extras;
-    std::vector<DItem> items;
-    std::vector<DNode> nodes;
     std::vector<DMaterial> mats;
     std::vector<DPattern> pats;
     std::vector<DLight> lights;
@@ -79,6 +77,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         const float* m = d->mat_param + 8 * i;
         out.mats.push_back(DMaterial{m[0], m[1], m[2], m[3], m[4], m[5], m[6], d->mat_pattern[i]});
     }
+    std::vector<DPrim> prims;  // by primitive index; moved into stream order below
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         if (d->prim_type[i] > RT_PRIM_SMOOTH_TRIANGLE) {
             err = "unknown primitive tag";
@@ -98,18 +97,9 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
             p.extra = static_cast<uint32_t>(out.extras.size());
             out.extras.push_back(e);
         }
-        out.prims.push_back(p);
+        prims.push_back(p);
     }
     if (out.extras.empty()) out.extras.push_back(DExtra{});  // never hand a null table to the kernel
-    for (uint32_t i = 0; i < d->n_nodes; ++i) {
-        DNode n{};
-        for (int k = 0; k < 3; ++k) {
-            n.mn[k] = widen(d->node_min[3 * i + k], false);
-            n.mx[k] = widen(d->node_max[3 * i + k], true);
-        }
-        out.nodes.push_back(n);
-    }
-    if (out.nodes.empty()) out.nodes.push_back(DNode{});
     // Item tree: pre-order with forward skip links.  i < next <= n_items and proper nesting
     // guarantee that every traversal (which only ever moves to i+1 or next[i]) terminates.
     {
@@ -129,11 +119,23 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
                 if (prim_seen[ref]) return bad("primitive referenced by more than one item");
                 prim_seen[ref] = 1;
             }
-            out.items.push_back(DItem{ref, next});
+            if (ref & RT_ITEM_NODE) {
+                const uint32_t n = ref & ~RT_ITEM_NODE;
+                DPrim r{};
+                for (int k = 0; k < 3; ++k) {
+                    r.inv[k] = widen(d->node_min[3 * n + k], false);
+                    r.inv[3 + k] = widen(d->node_max[3 * n + k], true);
+                }
+                r.type = REC_NODE;
+                r.material = next;
+                out.recs.push_back(r);
+            } else {
+                out.recs.push_back(prims[ref]);
+            }
         }
     }
     out.n_items = d->n_items;
-    if (out.items.empty()) out.items.push_back(DItem{0, 1});  // placeholder, n_items stays 0
+    if (out.recs.empty()) out.recs.push_back(DPrim{});  // placeholder, n_items stays 0
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         if (d->light_type[i] > RT_LIGHT_AREA) {
             err = "unknown light tag";

@@ -31,28 +31,28 @@ struct Closest {
     float t, u, v;
 };
 
+// visit(i, record) -> keep going?   Records are walked in stream order; a node whose box the ray's
+// LINE misses is jumped over (its `next` link is kept in `material`).
 template <class Visit>
 void traverse(const Sim& s, const Ray& ray, Visit&& visit) {
     uint32_t i = 0;
     while (i < s.ps.n_items) {
-        DItem it = s.ps.items[i];
-        if (it.ref & kItemNode) {
-            i = node_hit(s.ps.nodes[it.ref & ~kItemNode], ray.o, ray.d) ? i + 1 : it.next;
+        const DPrim& r = s.ps.recs[i];
+        if (r.type == REC_NODE) {
+            i = node_hit(r, ray.o, ray.d) ? i + 1 : r.material;
             continue;
         }
-        const DPrim& p = s.ps.prims[it.ref];
-        Hits h;
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == it.ref, h);
-        if (!visit(it.ref, p, h)) return;
+        if (!visit(i, r)) return;
         ++i;
     }
 }
 
 Closest closest_hit(const Sim& s, const Ray& ray) {
     Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
-    traverse(s, ray, [&](uint32_t prim, const DPrim&, const Hits& h) {
-        for (int k = 0; k < h.n; ++k)
-            if (closer_hit(h.t[k], c.t)) c = Closest{prim, h.t[k], h.u, h.v};
+    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int, float t, float u, float v) {
+            if (closer_hit(t, c.t)) c = Closest{prim, t, u, v};
+        });
         return true;
     });
     return c;
@@ -61,9 +61,10 @@ Closest closest_hit(const Sim& s, const Ray& ray) {
 // world.rs:73-92: shadowed iff the nearest positive hit is closer than the light
 bool occluded(const Sim& s, const Ray& ray, float dist) {
     bool occ = false;
-    traverse(s, ray, [&](uint32_t, const DPrim&, const Hits& h) {
-        for (int k = 0; k < h.n; ++k)
-            if (h.t[k] > 0.0f && h.t[k] < dist) occ = true;
+    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int, float t, float, float) {
+            if (t > 0.0f && t < dist) occ = true;
+        });
         return !occ;
     });
     return occ;
@@ -73,36 +74,15 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
 // odd number of its intersections precede the hit; `visited.last()` is the container whose last
 // crossing before the hit has the largest t.
 void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2) {
-    float best_t = -INFINITY, best_ior = 1.0f;
-    bool have_best = false, hit_in = false;
-    float hit_last = -INFINITY;
-    traverse(s, ray, [&](uint32_t prim, const DPrim& p, const Hits& h) {
-        int cnt = 0;
-        float last = -INFINITY;
-        int skip = -1;
-        if (prim == hit_prim) {  // the hit itself = its intersection closest to t_hit
-            float bd = INFINITY;
-            for (int k = 0; k < h.n; ++k)
-                if (fabsf(h.t[k] - t_hit) < bd) bd = fabsf(h.t[k] - t_hit), skip = k;
-        }
-        for (int k = 0; k < h.n; ++k) {
-            if (k == skip) continue;
-            if (precedes_hit(h.t[k], t_hit, prim, hit_prim)) ++cnt, last = fmaxf(last, h.t[k]);
-        }
-        if (cnt & 1) {
-            if (prim == hit_prim) hit_in = true, hit_last = last;
-            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = p.ior;
-        }
+    ContainerScan cs;
+    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+        Hits h;
+        h.t[0] = h.t[1] = h.t[2] = h.t[3] = RT_NOHIT;
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot] = t; });
+        cs.add(h, prim, p.ior, hit_prim, t_hit);
         return true;
     });
-    float excl = have_best ? best_ior : 1.0f;
-    if (hit_in) {
-        n1 = (!have_best || hit_last > best_t) ? hit_ior : best_ior;
-        n2 = excl;
-    } else {
-        n1 = excl;
-        n2 = hit_ior;
-    }
+    cs.finish(hit_ior, n1, n2);
 }
 
 struct PathNode {
@@ -126,7 +106,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
         bool alive = false;
         Closest c = closest_hit(s, cur.ray);
         if (c.prim != kNoPrim) {
-            const DPrim& p = s.ps.prims[c.prim];
+            const DPrim& p = s.ps.recs[c.prim];
             const DMaterial& m = s.ps.mats[p.material];
             HitInfo h = prepare_hit(p, s.ps.extras.data(), cur.ray, cur.ray.self == c.prim, c.t, c.u, c.v);
             V3 over = h.p + h.n * kEps;
@@ -142,10 +122,8 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
                 for (uint32_t cell = 0; cell < cells; ++cell) {
                     uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
                     float ju = 0.5f, jv = 0.5f;
-                    if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER) {
-                        ju = counter_jitter(pixel_key, cur.node, li, cell, 0);
-                        jv = counter_jitter(pixel_key, cur.node, li, cell, 1);
-                    }
+                    if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER)
+                        counter_jitter(pixel_key, cur.node, li, cell, ju, jv);
                     V3 lp = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, ju, jv) : v3(l.pos[0], l.pos[1], l.pos[2]);
                     V3 tl = lp - over;
                     float dist = sqrtf(dot(tl, tl));
