@@ -11,7 +11,7 @@ CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -Wall -Wextra -Wno-unused-parameter -f
 all: product oracle testhelpers
 product: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_scenes.so
 
-$(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
+$(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kernel.h raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) raytracer_amd/csrc/rt_amd.hip -o $@
 
