@@ -33,10 +33,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rt_math.h"
 
 #ifndef RT_EXP
 #define RT_EXP 0  // timing experiments only (scripts/exp_variants.sh): knock out one phase of the shading pass
+#endif
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 0  // request record i+1 while record i is processed (costs 16 SGPR copies per record)
 #endif
 
 namespace rtk {
@@ -71,12 +76,16 @@ __device__ __forceinline__ uint32_t rl_u(uint32_t v, int src) { return static_ca
 __device__ __forceinline__ float rl_f(float v, int src) { return __uint_as_float(rl_u(__float_as_uint(v), src)); }
 __device__ __forceinline__ V3 rl_v3(V3 v, int src) { return V3{rl_f(v.x, src), rl_f(v.y, src), rl_f(v.z, src)}; }
 
-// Wave-uniform walk over the record stream.  `live` lanes take part; visit(index, record) returns
-// whether the lane wants to continue.  Loop control depends only on ballots and on record fields,
-// so the index and the whole record stay in SGPRs; the record that follows in the stream is
-// requested before the current one is processed (wasted only when a group subtree is jumped).
+// Wave-uniform walk over the record stream.  `live` lanes take part; visit(index, record, self)
+// returns whether the lane wants to continue.  Loop control depends only on ballots and on record
+// fields, so the index and the whole record stay in SGPRs (scalar loads).  At the primitive a
+// lane's ray STARTS on (`self_prim`, rt_math.h "self"; kNoPrim = none) the visitor is called with
+// self = true in a block of its own: the lanes of a cooperative shadow pass share that primitive,
+// so the two variants of the intersection code almost never run in the same iteration.  With 4
+// waves per SIMD the load latency is covered by the other waves; requesting record i+1 ahead
+// (RT_PREFETCH) measured slower because of the 16 SGPR copies per record.
 template <class Visit>
-__device__ __forceinline__ void traverse(const KScene& sc, const Ray& ray, bool live, Visit&& visit) {
+__device__ __forceinline__ void traverse(const KScene& sc, V3 ro, V3 rd, uint32_t self_prim, bool live, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
     uint32_t i = 0;
@@ -85,19 +94,28 @@ __device__ __forceinline__ void traverse(const KScene& sc, const Ray& ray, bool 
     for (;;) {
         if (!wave_any(live)) break;
         const uint32_t seq = i + 1u;
+#if RT_PREFETCH
         const DPrim nxt = sc.recs[seq < n ? seq : i];
+#endif
         const bool part = live && i >= skip;
         uint32_t to = seq;
         if (rec.type == REC_NODE) {
-            const bool enter = part && node_hit(rec, ray.o, ray.d);
+            const bool enter = part && node_hit(rec, ro, rd);
             if (part && !enter) skip = rec.material;
             if (!wave_any(enter)) to = rec.material;
-        } else if (part) {
-            live = visit(i, rec);
+        } else {
+            const bool on_self = part && i == self_prim;
+            if (wave_any(on_self)) {
+                if (on_self) live = visit(i, rec, std::true_type{});
+            }
+            if (part && !on_self) live = visit(i, rec, std::false_type{});
         }
         if (to >= n) break;
+#if RT_PREFETCH
         if (to == seq) rec = nxt;
-        else rec = sc.recs[to];
+        else
+#endif
+            rec = sc.recs[to];
         i = to;
     }
 }
@@ -105,10 +123,11 @@ __device__ __forceinline__ void traverse(const KScene& sc, const Ray& ray, bool 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live) {
     bool occ = false;
-    traverse(sc, ray, live, [&](uint32_t prim, const DPrim& p) {
-        intersect_prim(p, sc.extras, ray, ray.self == prim, [&](int, float t, float, float) {
-            if (t > 0.0f && t < dist) occ = true;
-        });
+    traverse(sc, ray.o, ray.d, ray.self, live, [&](uint32_t, const DPrim& p, auto self) {
+        if (decltype(self)::value)
+            intersect_prim(p, sc.extras, ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+        else
+            occ = occludes_prim(p, sc.extras, ray.o, ray.d, dist);
         return !occ;
     });
     return occ;
@@ -162,8 +181,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         // ---------------------------------------------------------------- trace (world.rs:24-41)
         uint32_t hit_prim = kNoPrim;
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
-        traverse(sc, cur, active, [&](uint32_t prim, const DPrim& p) {
-            intersect_prim(p, sc.extras, cur, cur.self == prim, [&](int, float t, float u, float v) {
+        traverse(sc, cur.o, cur.d, cur.self, active, [&](uint32_t prim, const DPrim& p, auto self) {
+            intersect_prim(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
                 if (closer_hit(t, hit_t)) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;  // intersection.rs:105-120
             });
             return true;
@@ -196,10 +215,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         // ---------------------------------------------------------------- containers (intersection.rs:71-103)
         if (wave_any(need_n)) {
             ContainerScan cs;
-            traverse(sc, cur, need_n, [&](uint32_t prim, const DPrim& p) {
+            traverse(sc, cur.o, cur.d, cur.self, need_n, [&](uint32_t prim, const DPrim& p, auto self) {
                 Hits hh;
                 hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
-                intersect_prim(p, sc.extras, cur, cur.self == prim, [&](int slot, float t, float, float) { hh.t[slot] = t; });
+                intersect_prim(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t; });
                 cs.add(hh, prim, p.ior, hit_prim, hit_t);
                 return true;
             });

@@ -141,7 +141,9 @@ RT_HD bool approx(float a, float b) {
     return fabsf(a - b) <= kEps;
 }
 // partial_cmp(a,b) == Greater  (NaN => Greater, float.rs:29-37)
-RT_HD bool cmp_greater(float a, float b) { return !approx(a, b) && !(a < b); }
+// (Without approx()'s equal-infinities case: max_by3/min_by3 only use the comparison to pick one of
+// two VALUES, and two infinities of the same sign are the same value whichever is picked.)
+RT_HD bool cmp_greater(float a, float b) { return !(fabsf(a - b) <= kEps) & !(a < b); }
 // cube.rs:63-73: max_by keeps the last of approx-equal maxima, min_by the first of approx-equal minima
 RT_HD float max_by3(float a, float b, float c) {
     float m = cmp_greater(a, b) ? a : b;
@@ -165,6 +167,12 @@ RT_HD float min_by3(float a, float b, float c) {
 // cannot.
 RT_HD float tie_window(float t) { return kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
 RT_HD bool closer_hit(float t, float best) { return t > 0.0f && t < best - tie_window(t); }  // best may be +inf
+// The same rule when candidates do NOT arrive in stream order (the primitive a ray starts on is
+// tested first): an approximately equal t wins only if its primitive comes earlier in the stream.
+RT_HD bool closer_hit(float t, uint32_t prim, float best, uint32_t best_prim) {
+    float w = tie_window(t);
+    return (t > 0.0f) & ((t < best - w) | ((prim < best_prim) & (t <= best + w)));
+}
 // Does an intersection of primitive `prim` come before the hit (hit_prim, t_hit) in that sorted list?
 RT_HD bool precedes_hit(float t, float t_hit, uint32_t prim, uint32_t hit_prim) {
     return (fabsf(t - t_hit) <= tie_window(t_hit)) ? (prim < hit_prim) : (t < t_hit);
@@ -366,6 +374,40 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
             const float* e = extras[p.extra].f;
             isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), emit);
             break;
+        }
+    }
+}
+
+// Shadow rays only ask "is there an intersection with 0 < t < dist" (world.rs:73-92: the nearest
+// positive hit is closer than the light iff ANY positive hit is).  For a ray that does NOT start on
+// the primitive the three common shapes answer without a branch; the others go through the emitter.
+RT_HD bool in_range(float t, float dist) { return (t > 0.0f) & (t < dist); }
+RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, float dist) {
+    switch (p.type) {
+        case PRIM_PLANE: {
+            float oy = fmaf(p.inv[4], ro.x, fmaf(p.inv[5], ro.y, fmaf(p.inv[6], ro.z, p.inv[7])));
+            float dy = fmaf(p.inv[4], rd.x, fmaf(p.inv[5], rd.y, p.inv[6] * rd.z));
+            return !(fabsf(dy) <= kEps) & in_range(-oy * rcp_f(dy), dist);
+        }
+        case PRIM_SPHERE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tc, half;
+            V3 l;
+            bool ok = sphere_foot(o, d, dot(d, d), tc, l, half);
+            return ok & (in_range(tc - half, dist) | in_range(tc + half, dist));
+        }
+        case PRIM_CUBE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tmin, tmax;
+            isect_box(v3(-1.0f, -1.0f, -1.0f) - o, v3(1.0f, 1.0f, 1.0f) - o, d, tmin, tmax);
+            return !(tmin > tmax) & (in_range(tmin, dist) | in_range(tmax, dist));
+        }
+        default: {
+            bool occ = false;
+            Ray r;
+            r.o = ro, r.d = rd, r.self = kNoPrim, r.q = v3(0.0f, 0.0f, 0.0f), r.dq = v3(0.0f, 0.0f, 0.0f);
+            intersect_prim(p, extras, r, false, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+            return occ;
         }
     }
 }

@@ -50,7 +50,7 @@ void traverse(const Sim& s, const Ray& ray, Visit&& visit) {
 Closest closest_hit(const Sim& s, const Ray& ray) {
     Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
     traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int, float t, float u, float v) {
+        intersect_prim(p, s.ps.extras.data(), ray, prim == ray.self, [&](int, float t, float u, float v) {
             if (closer_hit(t, c.t)) c = Closest{prim, t, u, v};
         });
         return true;
@@ -62,9 +62,10 @@ Closest closest_hit(const Sim& s, const Ray& ray) {
 bool occluded(const Sim& s, const Ray& ray, float dist) {
     bool occ = false;
     traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int, float t, float, float) {
-            if (t > 0.0f && t < dist) occ = true;
-        });
+        if (prim == ray.self)
+            intersect_prim(p, s.ps.extras.data(), ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+        else
+            occ = occludes_prim(p, s.ps.extras.data(), ray.o, ray.d, dist);
         return !occ;
     });
     return occ;
