@@ -81,6 +81,7 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
 
 struct rt_scene {
     int device = 0;
+    bool exotic = false;  // some primitive is a cylinder or a triangle
     KScene k{};
     std::vector<void*> owned;
     unsigned long long* counters = nullptr;
@@ -106,11 +107,14 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.n_tiles = P.tiles_x * tiles_y;
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t blocks = (P.n_tiles + 3u) / 4u;  // 4 waves (tiles) per 256-thread block
+    // four instantiations: with/without counters x with/without cylinder-triangle code
     if (stats) {
         HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(256), 0, stream, P);
+        if (s->exotic) hipLaunchKernelGGL((render_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((render_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, P);
     } else {
-        hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(256), 0, stream, P);
+        if (s->exotic) hipLaunchKernelGGL((render_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((render_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, P);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -195,6 +199,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.pats, &s->k.pats, s->owned);
     if (rc == RT_OK) rc = upload(ps.lights, &s->k.lights, s->owned);
     s->k.n_items = ps.n_items;
+    for (const DPrim& r : ps.recs) s->exotic |= r.type >= PRIM_CYLINDER && r.type != REC_NODE;
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {
         void* c = nullptr;

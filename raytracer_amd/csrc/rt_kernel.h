@@ -121,13 +121,14 @@ __device__ __forceinline__ void traverse(const KScene& sc, V3 ro, V3 rd, uint32_
 }
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
+template <bool EXOTIC>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live) {
     bool occ = false;
     traverse(sc, ray.o, ray.d, ray.self, live, [&](uint32_t, const DPrim& p, auto self) {
         if (decltype(self)::value)
-            intersect_prim(p, sc.extras, ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+            intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
         else
-            occ = occludes_prim(p, sc.extras, ray.o, ray.d, dist);
+            occ = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
         return !occ;
     });
     return occ;
@@ -143,7 +144,8 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // 4 waves per SIMD (<= 128 VGPRs): the kernel waits on scalar loads, cross-lane traffic and
 // transcendental latency, and measured 35 % faster at 4 waves/SIMD than at 2
 // (profiles/r01_occupancy_sweep.txt); 5 and more spill too much.
-template <bool STATS>
+// EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim).
+template <bool STATS, bool EXOTIC>
 __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         uint32_t hit_prim = kNoPrim;
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
         traverse(sc, cur.o, cur.d, cur.self, active, [&](uint32_t prim, const DPrim& p, auto self) {
-            intersect_prim(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
+            intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
                 if (closer_hit(t, hit_t)) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;  // intersection.rs:105-120
             });
             return true;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             const DPrim p = sc.recs[hit_prim];
             mi = p.material;
             const DMaterial m = sc.mats[mi];
-            const HitInfo h = prepare_hit(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
+            const HitInfo h = prepare_hit<EXOTIC>(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
             over = h.p + h.n * kEps, nrm = h.n, hq = h.q, hdq = h.dq;
             pc = pattern_color(sc.pats[m.pattern], h.q + h.dq);  // pattern at over_point (material.rs:127)
             need_n = depth > 0u && m.transparency > 0.0f;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             traverse(sc, cur.o, cur.d, cur.self, need_n, [&](uint32_t prim, const DPrim& p, auto self) {
                 Hits hh;
                 hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
-                intersect_prim(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t; });
+                intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t; });
                 cs.add(hh, prim, p.ior, hit_prim, hit_t);
                 return true;
             });
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
                 Ray sr;
                 sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = hq, sr.dq = hdq;
-                const bool occ = occluded(sc, sr, dist, cast);
+                const bool occ = occluded<EXOTIC>(sc, sr, dist, cast);
                 lit = occ ? 0.0f : 1.0f;
                 if (has_hit) phong_cell(lp, over, nrm, eye, m_shininess, sum_d, sum_s);
                 if (STATS && cast) c_shadow++;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        const bool occ = occluded(sc, sr, dist, cast);
+                        const bool occ = occluded<EXOTIC>(sc, sr, dist, cast);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);

