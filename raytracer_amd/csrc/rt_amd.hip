@@ -82,6 +82,7 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
 struct rt_scene {
     int device = 0;
     bool exotic = false;  // some primitive is a cylinder or a triangle
+    bool tree = false;    // the stream has hierarchy nodes or Group gates
     KScene k{};
     std::vector<void*> owned;
     unsigned long long* counters = nullptr;
@@ -107,15 +108,14 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.n_tiles = P.tiles_x * tiles_y;
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t blocks = (P.n_tiles + 3u) / 4u;  // 4 waves (tiles) per 256-thread block
-    // four instantiations: with/without counters x with/without cylinder-triangle code
-    if (stats) {
-        HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
-        if (s->exotic) hipLaunchKernelGGL((render_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL((render_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, P);
-    } else {
-        if (s->exotic) hipLaunchKernelGGL((render_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL((render_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, P);
-    }
+    // eight instantiations: counters x cylinder/triangle code x hierarchy/gate code
+    if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
+    const int variant = (stats ? 4 : 0) | (s->exotic ? 2 : 0) | (s->tree ? 1 : 0);
+    void (*kernels[8])(const KParams) = {render_kernel<false, false, false>, render_kernel<false, false, true>,
+                                         render_kernel<false, true, false>,  render_kernel<false, true, true>,
+                                         render_kernel<true, false, false>,  render_kernel<true, false, true>,
+                                         render_kernel<true, true, false>,   render_kernel<true, true, true>};
+    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(256), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -194,12 +194,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (!s) return fail(RT_ERR_CAPACITY, "out of host memory");
     s->device = device;
     rc = upload(ps.recs, &s->k.recs, s->owned);
+    if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
+    if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
+    if (rc == RT_OK) rc = upload(ps.gates, &s->k.gates, s->owned);
     if (rc == RT_OK) rc = upload(ps.extras, &s->k.extras, s->owned);
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
     if (rc == RT_OK) rc = upload(ps.pats, &s->k.pats, s->owned);
     if (rc == RT_OK) rc = upload(ps.lights, &s->k.lights, s->owned);
     s->k.n_items = ps.n_items;
-    for (const DPrim& r : ps.recs) s->exotic |= r.type >= PRIM_CYLINDER && r.type != REC_NODE;
+    s->k.has_gates = ps.has_gates, s->k.has_bvh = ps.has_bvh;
+    s->exotic = ps.exotic;
+    s->tree = ps.has_bvh || ps.has_gates;
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {
         void* c = nullptr;

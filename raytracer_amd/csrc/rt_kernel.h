@@ -47,12 +47,16 @@
 namespace rtk {
 
 struct KScene {
-    const DPrim* recs;  // the traversal stream (rt_math.h)
+    const DPrim* recs;      // the traversal stream (rt_math.h, rt_pack.h)
+    const uint32_t* order;  // per record: world.objects position of the primitive (tie order)
+    const uint32_t* gate;   // per record: innermost enclosing Group of the caller's tree, or kNoGate
+    const DGate* gates;
     const DExtra* extras;
     const DMaterial* mats;
     const DPattern* pats;
     const DLight* lights;
     uint32_t n_items, n_lights;
+    uint32_t has_gates, has_bvh;
 };
 struct KParams {
     KScene sc;
@@ -77,19 +81,21 @@ __device__ __forceinline__ float rl_f(float v, int src) { return __uint_as_float
 __device__ __forceinline__ V3 rl_v3(V3 v, int src) { return V3{rl_f(v.x, src), rl_f(v.y, src), rl_f(v.z, src)}; }
 
 // Wave-uniform walk over the record stream.  `live` lanes take part; visit(index, record, self)
-// returns whether the lane wants to continue.  Loop control depends only on ballots and on record
-// fields, so the index and the whole record stay in SGPRs (scalar loads).  At the primitive a
+// returns whether the lane wants to continue; enter(node record) says whether the lane's ray can
+// meet anything inside a node's box.  Loop control depends only on ballots and on record fields, so
+// the index and the whole record stay in SGPRs (scalar loads); a lane that misses a node's box sits
+// out its subtree (`skip`), and the wave jumps a subtree no lane entered.  At the primitive a
 // lane's ray STARTS on (`self_prim`, rt_math.h "self"; kNoPrim = none) the visitor is called with
 // self = true in a block of its own: the lanes of a cooperative shadow pass share that primitive,
 // so the two variants of the intersection code almost never run in the same iteration.  With 4
 // waves per SIMD the load latency is covered by the other waves; requesting record i+1 ahead
 // (RT_PREFETCH) measured slower because of the 16 SGPR copies per record.
-template <class Visit>
-__device__ __forceinline__ void traverse(const KScene& sc, V3 ro, V3 rd, uint32_t self_prim, bool live, Visit&& visit) {
+template <bool TREE, class Enter, class Visit>
+__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
     uint32_t i = 0;
-    uint32_t skip = 0;  // per lane: sit out records below this index (a group whose box it missed)
+    uint32_t skip = 0;  // per lane: sit out records below this index (a node whose box it missed)
     DPrim rec = sc.recs[0];
     for (;;) {
         if (!wave_any(live)) break;
@@ -99,8 +105,8 @@ __device__ __forceinline__ void traverse(const KScene& sc, V3 ro, V3 rd, uint32_
 #endif
         const bool part = live && i >= skip;
         uint32_t to = seq;
-        if (rec.type == REC_NODE) {
-            const bool enter = part && node_hit(rec, ro, rd);
+        if (TREE && rec.type == REC_NODE) {
+            const bool enter = part && enter_node(rec);
             if (part && !enter) skip = rec.material;
             if (!wave_any(enter)) to = rec.material;
         } else {
@@ -121,16 +127,23 @@ __device__ __forceinline__ void traverse(const KScene& sc, V3 ro, V3 rd, uint32_
 }
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
-template <bool EXOTIC>
+template <bool EXOTIC, bool TREE>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live) {
     bool occ = false;
-    traverse(sc, ray.o, ray.d, ray.self, live, [&](uint32_t, const DPrim& p, auto self) {
-        if (decltype(self)::value)
-            intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
-        else
-            occ = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
-        return !occ;
-    });
+    V3 inv_d = v3(0.0f, 0.0f, 0.0f);
+    if ((TREE && sc.has_bvh)) inv_d = inv_dir(ray.d);
+    traverse<TREE>(
+        sc, ray.self, live, [&](const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); },
+        [&](uint32_t prim, const DPrim& p, auto self) {
+            bool hit = false;
+            if (decltype(self)::value)
+                intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+            else
+                hit = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
+            if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
+            occ = hit;
+            return !occ;
+        });
     return occ;
 }
 
@@ -144,8 +157,9 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // 4 waves per SIMD (<= 128 VGPRs): the kernel waits on scalar loads, cross-lane traffic and
 // transcendental latency, and measured 35 % faster at 4 waves/SIMD than at 2
 // (profiles/r01_occupancy_sweep.txt); 5 and more spill too much.
-// EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim).
-template <bool STATS, bool EXOTIC>
+// EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
+// hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
+template <bool STATS, bool EXOTIC, bool TREE>
 __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -183,12 +197,21 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         // ---------------------------------------------------------------- trace (world.rs:24-41)
         uint32_t hit_prim = kNoPrim;
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
-        traverse(sc, cur.o, cur.d, cur.self, active, [&](uint32_t prim, const DPrim& p, auto self) {
-            intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
-                if (closer_hit(t, hit_t)) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;  // intersection.rs:105-120
+        V3 inv_d = v3(0.0f, 0.0f, 0.0f);
+        if ((TREE && sc.has_bvh)) inv_d = inv_dir(cur.d);
+        traverse<TREE>(
+            sc, cur.self, active,
+            [&](const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); },
+            [&](uint32_t prim, const DPrim& p, auto self) {
+                intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
+                    // intersection.rs:105-120: smallest t > 0, world.objects order among approximately equal ones
+                    bool better = closer_hit(t, hit_t);
+                    if (!better && (TREE && sc.has_bvh) && hit_prim != kNoPrim && ties_hit(t, hit_t)) better = sc.order[prim] < sc.order[hit_prim];
+                    if (better && (TREE && sc.has_gates)) better = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);  // group.rs:107
+                    if (better) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;
+                });
+                return true;
             });
-            return true;
-        });
         const bool has_hit = active && hit_prim != kNoPrim;
         const uint32_t depth = P.max_depth - level_of(node);  // remaining recursion depth of this node
 
@@ -217,13 +240,19 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         // ---------------------------------------------------------------- containers (intersection.rs:71-103)
         if (wave_any(need_n)) {
             ContainerScan cs;
-            traverse(sc, cur.o, cur.d, cur.self, need_n, [&](uint32_t prim, const DPrim& p, auto self) {
-                Hits hh;
-                hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
-                intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t; });
-                cs.add(hh, prim, p.ior, hit_prim, hit_t);
-                return true;
-            });
+            const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
+            traverse<TREE>(
+                sc, cur.self, need_n,
+                [&](const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, INFINITY); },  // every crossing counts
+                [&](uint32_t prim, const DPrim& p, auto self) {
+                    Hits hh;
+                    hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
+                    bool any = false;
+                    intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t, any = true; });
+                    if (any && (TREE && sc.has_gates)) any = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);
+                    if (any) cs.add(hh, prim == hit_prim, TREE ? sc.order[prim] : prim, p.ior, ord_hit, hit_t);
+                    return true;
+                });
             if (need_n) {
                 cs.finish(m_ior, n1, n2);
                 if (STATS) c_container++;
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
                 Ray sr;
                 sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = hq, sr.dq = hdq;
-                const bool occ = occluded<EXOTIC>(sc, sr, dist, cast);
+                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast);
                 lit = occ ? 0.0f : 1.0f;
                 if (has_hit) phong_cell(lp, over, nrm, eye, m_shininess, sum_d, sum_s);
                 if (STATS && cast) c_shadow++;
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        const bool occ = occluded<EXOTIC>(sc, sr, dist, cast);
+                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);

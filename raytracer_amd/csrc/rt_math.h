@@ -167,15 +167,13 @@ RT_HD float min_by3(float a, float b, float c) {
 // cannot.
 RT_HD float tie_window(float t) { return kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
 RT_HD bool closer_hit(float t, float best) { return t > 0.0f && t < best - tie_window(t); }  // best may be +inf
-// The same rule when candidates do NOT arrive in stream order (the primitive a ray starts on is
-// tested first): an approximately equal t wins only if its primitive comes earlier in the stream.
-RT_HD bool closer_hit(float t, uint32_t prim, float best, uint32_t best_prim) {
-    float w = tie_window(t);
-    return (t > 0.0f) & ((t < best - w) | ((prim < best_prim) & (t <= best + w)));
-}
-// Does an intersection of primitive `prim` come before the hit (hit_prim, t_hit) in that sorted list?
-RT_HD bool precedes_hit(float t, float t_hit, uint32_t prim, uint32_t hit_prim) {
-    return (fabsf(t - t_hit) <= tie_window(t_hit)) ? (prim < hit_prim) : (t < t_hit);
+// Candidates do not always arrive in world.objects order (the device walks its own hierarchy): an
+// approximately equal t is a TIE, which the caller resolves by the primitives' order keys.
+RT_HD bool ties_hit(float t, float best) { return t > 0.0f && fabsf(t - best) <= tie_window(t); }
+// Does an intersection of a primitive come before the hit (t_hit) in that sorted list?  `ord` /
+// `ord_hit` are the primitives' positions in world.objects order (DESIGN.md "order keys").
+RT_HD bool precedes_hit(float t, float t_hit, uint32_t ord, uint32_t ord_hit) {
+    return (fabsf(t - t_hit) <= tie_window(t_hit)) ? (ord < ord_hit) : (t < t_hit);
 }
 
 // A ray in world space plus what it knows about the primitive it starts on.
@@ -419,15 +417,45 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
     }
 }
 
-// Group box test on the WORLD ray (group.rs:107, bounding_box.rs:81-84): hit iff tmin < tmax on
-// the whole line.  The device boxes are widened by a few ulps at upload so FP32 rounding cannot
-// cull a child the f64 test would have entered.  A node record keeps min in inv[0..2], max in
-// inv[3..5] and its skip link in `material`.
-RT_HD bool node_hit(const DPrim& n, V3 o, V3 d) {
-    float tmin, tmax;
-    isect_box(v3(n.inv[0], n.inv[1], n.inv[2]) - o, v3(n.inv[3], n.inv[4], n.inv[5]) - o, d, tmin, tmax);
-    return tmin < tmax;
+// ---------------------------------------------------------------------------------------------
+// Groups.  The reference enters a Group's children only if the ray's LINE hits the group's box
+// (group.rs:107, bounding_box.rs:81-84: tmin < tmax, strict, approximate max_by/min_by) — so a
+// primitive inside groups G1 > G2 > ... is visible to a ray iff every one of those tests passes.
+// The device does not walk the caller's tree (its leaves may hold hundreds of children): it walks
+// its own bounding-volume hierarchy over the primitives (rt_pack.h) and keeps the caller's boxes as
+// GATES, checked only when a primitive's own test found something.  Same visible set, same image.
+struct DGate {  // 32 B: one Group of the caller's tree
+    float mn[3];
+    uint32_t parent;  // enclosing Group's gate, or kNoGate
+    float mx[3];
+    uint32_t pad;
+};
+constexpr uint32_t kNoGate = 0xFFFFFFFFu;
+
+RT_HD bool gates_pass(const DGate* gates, uint32_t g, V3 o, V3 d) {
+    while (g != kNoGate) {
+        const DGate G = gates[g];
+        float tmin, tmax;
+        isect_box(v3(G.mn[0], G.mn[1], G.mn[2]) - o, v3(G.mx[0], G.mx[1], G.mx[2]) - o, d, tmin, tmax);
+        if (!(tmin < tmax)) return false;
+        g = G.parent;
+    }
+    return true;
 }
+
+// A node of the device's own hierarchy: box min in inv[0..2], max in inv[3..5] (rounded outwards),
+// skip link in `material`.  Plain slab test on the parameter interval [t_lo, t_hi]; a NaN from
+// 0 * inf (origin on a slab plane, direction parallel to it) drops out of min/max, which keeps the
+// test conservative.  inv_d = 1 / direction, per component.
+RT_HD bool bvh_node_hit(const DPrim& n, V3 o, V3 inv_d, float t_lo, float t_hi) {
+    float x0 = (n.inv[0] - o.x) * inv_d.x, x1 = (n.inv[3] - o.x) * inv_d.x;
+    float y0 = (n.inv[1] - o.y) * inv_d.y, y1 = (n.inv[4] - o.y) * inv_d.y;
+    float z0 = (n.inv[2] - o.z) * inv_d.z, z1 = (n.inv[5] - o.z) * inv_d.z;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_hi));
+    return tn <= tf;
+}
+RT_HD V3 inv_dir(V3 d) { return v3(rcp_f(d.x), rcp_f(d.y), rcp_f(d.z)); }
 
 // intersection.rs:71-103 without the sorted list.  The reference walks the sorted intersections up
 // to the hit, toggling each object in a container list; n1 is the material of the list's last entry
@@ -438,8 +466,8 @@ struct ContainerScan {
     float best_t = -INFINITY, best_ior = 1.0f, hit_last = -INFINITY;
     bool have_best = false, hit_in = false;
 
-    RT_HD void add(const Hits& h, uint32_t prim, float ior, uint32_t hit_prim, float t_hit) {
-        const bool is_hit_prim = prim == hit_prim;
+    // ord / ord_hit: world.objects positions of this primitive and of the hit one
+    RT_HD void add(const Hits& h, bool is_hit_prim, uint32_t ord, float ior, uint32_t ord_hit, float t_hit) {
         int skipk = -1;  // the hit itself = the hit primitive's intersection closest to t_hit
         float bd = INFINITY;
         for (int k = 0; k < 4; ++k)
@@ -447,7 +475,7 @@ struct ContainerScan {
         int cnt = 0;
         float last = -INFINITY;
         for (int k = 0; k < 4; ++k)
-            if (k != skipk && h.t[k] == h.t[k] && precedes_hit(h.t[k], t_hit, prim, hit_prim)) ++cnt, last = fmaxf(last, h.t[k]);
+            if (k != skipk && h.t[k] == h.t[k] && precedes_hit(h.t[k], t_hit, ord, ord_hit)) ++cnt, last = fmaxf(last, h.t[k]);
         if (cnt & 1) {
             if (is_hit_prim) hit_in = true, hit_last = last;
             else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = ior;

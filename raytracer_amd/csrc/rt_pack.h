@@ -1,9 +1,21 @@
-// rt_pack.h — host side of rt_scene_create: validates an rt_scene_desc and repacks its SoA
-// arrays into the device records of rt_math.h (array-of-64-byte-records: one scalar load per
-// wave-uniform primitive, one cache line per divergent gather).  Pure C++ (no HIP), so the
-// test-only host simulator can reuse exactly the same tables.
+// rt_pack.h — host side of rt_scene_create: validates an rt_scene_desc and compiles it into the
+// device tables of rt_math.h.  Pure C++ (no HIP), so the test-only host simulator reuses exactly the
+// same tables.
+//
+// The traversal stream.  The caller's scene is a list of objects, some of them Groups with a box
+// (world.rs:32-41, group.rs:106-119); the reference tests every object, and a Group's children when
+// the ray's line hits the Group's box.  What a ray can see is therefore: every primitive whose
+// enclosing Groups' box tests all pass.  The device keeps that rule (the Groups become GATES,
+// rt_math.h) but does not walk the caller's tree, whose leaves may hold hundreds of children
+// (Group::divide(256) in examples/multiple_glass_and_metallic_spheres.rs:104).  It walks its own
+// bounding-volume hierarchy instead: bounded primitives (spheres, cubes, bounded cylinders,
+// triangles) are sorted into a binary tree of world-space boxes with at most two primitives per
+// leaf, unbounded ones (planes, infinite cylinders) stay at the top, and the whole thing is laid out
+// as ONE array of 64-byte records in depth-first pre-order with skip links.  Scenes with a handful
+// of primitives and no Groups are laid out flat, in world.objects order.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -15,24 +27,162 @@
 namespace rtk {
 
 struct PackedScene {
-    std::vector<DPrim> recs;  // the traversal stream: one record per item, in item order
+    std::vector<DPrim> recs;      // the traversal stream
+    std::vector<uint32_t> order;  // per record: the primitive's position in world.objects order (nodes: 0)
+    std::vector<uint32_t> gate;   // per record: innermost enclosing Group (index into gates) or kNoGate
+    std::vector<DGate> gates;     // the caller's Groups
     std::vector<DExtra> extras;
     std::vector<DMaterial> mats;
     std::vector<DPattern> pats;
     std::vector<DLight> lights;
     uint32_t n_items = 0, n_lights = 0;  // real counts (the vectors are padded to be non-empty)
-    uint32_t max_cells = 1;             // largest usteps*vsteps over the lights
+    uint32_t max_cells = 1;              // largest usteps*vsteps over the lights
+    bool has_gates = false, has_bvh = false, exotic = false;
 };
 
-// Widen a box bound outwards by a relative 4e-6 (+ a tiny absolute term): the slab test on the
-// device runs in FP32, and a child whose intersection exists in f64 must never be culled because
-// the box test rounded the other way.  Culling is purely an optimisation — the reference's own
-// result is "every child whose line-box test passes", and boxes bound their children.
+constexpr uint32_t kFlatLimit = 8;  // at most this many primitives and no Groups: no hierarchy
+
+// Widen a box bound outwards by a relative 4e-6 (+ a tiny absolute term): the slab tests on the
+// device run in FP32, and nothing that intersects in f64 may be culled because a box test rounded
+// the other way.
 inline float widen(float v, bool up) {
     if (std::isinf(v) || std::isnan(v)) return v;
     float pad = std::fabs(v) * 4e-6f + 1e-6f;
     return up ? v + pad : v - pad;
 }
+
+struct HostBox {
+    double mn[3], mx[3];
+    bool bounded;
+    void add(const double p[3]) {
+        for (int k = 0; k < 3; ++k) mn[k] = std::min(mn[k], p[k]), mx[k] = std::max(mx[k], p[k]);
+    }
+    void merge(const HostBox& o) {
+        for (int k = 0; k < 3; ++k) mn[k] = std::min(mn[k], o.mn[k]), mx[k] = std::max(mx[k], o.mx[k]);
+    }
+    static HostBox empty() {
+        HostBox b;
+        for (int k = 0; k < 3; ++k) b.mn[k] = INFINITY, b.mx[k] = -INFINITY;
+        b.bounded = true;
+        return b;
+    }
+};
+
+// Inverse of a 3x4 affine (rows) in f64; false if singular.
+inline bool invert_affine(const float* m, double out[12]) {
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return false;
+    const double r = 1.0 / det;
+    double L[9] = {A * r, -(b * i - c * h) * r, (b * f - c * e) * r, B * r, (a * i - c * g) * r, -(a * f - c * d) * r,
+                   C * r, -(a * h - b * g) * r, (a * e - b * d) * r};
+    const double t[3] = {m[3], m[7], m[11]};
+    for (int k = 0; k < 3; ++k) {
+        out[4 * k + 0] = L[3 * k + 0], out[4 * k + 1] = L[3 * k + 1], out[4 * k + 2] = L[3 * k + 2];
+        out[4 * k + 3] = -(L[3 * k + 0] * t[0] + L[3 * k + 1] * t[1] + L[3 * k + 2] * t[2]);
+    }
+    return true;
+}
+
+// World-space box of one primitive, from the SAME f32 transform_inverse the device intersects with.
+inline HostBox prim_world_box(uint32_t type, const float* inv, const float* param) {
+    HostBox box = HostBox::empty();
+    double fwd[12];
+    if (type == RT_PRIM_PLANE || !invert_affine(inv, fwd)) {
+        box.bounded = false;
+        return box;
+    }
+    auto put = [&](double x, double y, double z) {
+        double p[3];
+        for (int k = 0; k < 3; ++k) p[k] = fwd[4 * k] * x + fwd[4 * k + 1] * y + fwd[4 * k + 2] * z + fwd[4 * k + 3];
+        box.add(p);
+    };
+    if (type == RT_PRIM_TRIANGLE || type == RT_PRIM_SMOOTH_TRIANGLE) {
+        const float* v0 = param;
+        const float* e0 = param + 3;
+        const float* e1 = param + 6;
+        put(v0[0], v0[1], v0[2]);
+        put(double(v0[0]) + e0[0], double(v0[1]) + e0[1], double(v0[2]) + e0[2]);  // triangle.rs: e0 = v1 - v0
+        put(double(v0[0]) + e1[0], double(v0[1]) + e1[1], double(v0[2]) + e1[2]);
+    } else {
+        double y0 = -1.0, y1 = 1.0;
+        if (type == RT_PRIM_CYLINDER) {
+            y0 = param[0], y1 = param[1];
+            if (!std::isfinite(y0) || !std::isfinite(y1)) {
+                box.bounded = false;
+                return box;
+            }
+        }
+        for (int c = 0; c < 8; ++c) put((c & 1) ? 1.0 : -1.0, (c & 2) ? y1 : y0, (c & 4) ? 1.0 : -1.0);
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(box.mn[k]) || !std::isfinite(box.mx[k])) {
+            box.bounded = false;
+            return box;
+        }
+        // f64 -> f32 outwards, plus room for the FP32 intersection arithmetic
+        const double pad = 1e-5 * std::max(std::fabs(box.mn[k]), std::fabs(box.mx[k])) + 1e-5;
+        box.mn[k] -= pad, box.mx[k] += pad;
+    }
+    return box;
+}
+
+struct BvhBuild {
+    std::vector<HostBox> boxes;  // per bounded primitive (index into `ids`)
+    std::vector<uint32_t> ids;   // item index of each bounded primitive
+    std::vector<uint32_t> perm;  // working permutation
+    PackedScene* out = nullptr;
+    const std::vector<DPrim>* item_rec = nullptr;  // record of each item (primitives only)
+    const std::vector<uint32_t>* item_gate = nullptr;
+
+    void emit_prim(uint32_t k) {
+        const uint32_t item = ids[k];
+        out->recs.push_back((*item_rec)[item]);
+        out->order.push_back(item);
+        out->gate.push_back((*item_gate)[item]);
+    }
+    void build(uint32_t lo, uint32_t hi) {  // perm[lo, hi)
+        const uint32_t n = hi - lo;
+        if (n == 1) {
+            emit_prim(perm[lo]);
+            return;
+        }
+        HostBox all = HostBox::empty(), cen = HostBox::empty();
+        for (uint32_t k = lo; k < hi; ++k) {
+            const HostBox& b = boxes[perm[k]];
+            all.merge(b);
+            double c[3] = {0.5 * (b.mn[0] + b.mx[0]), 0.5 * (b.mn[1] + b.mx[1]), 0.5 * (b.mn[2] + b.mx[2])};
+            cen.add(c);
+        }
+        const size_t at = out->recs.size();
+        DPrim node{};
+        for (int k = 0; k < 3; ++k) {
+            node.inv[k] = widen(std::nextafter(static_cast<float>(all.mn[k]), -INFINITY), false);
+            node.inv[3 + k] = widen(std::nextafter(static_cast<float>(all.mx[k]), INFINITY), true);
+        }
+        node.type = REC_NODE;
+        out->recs.push_back(node);
+        out->order.push_back(0);
+        out->gate.push_back(kNoGate);
+        if (n <= 2) {
+            for (uint32_t k = lo; k < hi; ++k) emit_prim(perm[k]);
+        } else {
+            int axis = 0;
+            double ext = -1.0;
+            for (int k = 0; k < 3; ++k)
+                if (cen.mx[k] - cen.mn[k] > ext) ext = cen.mx[k] - cen.mn[k], axis = k;
+            const uint32_t mid = lo + n / 2;
+            std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, [&](uint32_t a, uint32_t b) {
+                const double ca = boxes[a].mn[axis] + boxes[a].mx[axis], cb = boxes[b].mn[axis] + boxes[b].mx[axis];
+                return ca < cb || (ca == cb && a < b);
+            });
+            build(lo, mid);
+            build(mid, hi);
+        }
+        out->recs[at].material = static_cast<uint32_t>(out->recs.size());  // skip link
+    }
+};
 
 // Returns RT_OK or a negative rt_status; `err` receives the message.
 inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err) {
@@ -54,7 +204,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         err = "too many lights (RT_MAX_LIGHTS)";
         return RT_ERR_CAPACITY;
     }
-    if (d->n_prims >= 0x7FFFFFFFu || d->n_items >= 0x7FFFFFFFu) {
+    if (d->n_prims >= 0x7FFFFFFFu || d->n_items >= 0x3FFFFFFFu) {
         err = "too many primitives";
         return RT_ERR_CAPACITY;
     }
@@ -77,7 +227,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         const float* m = d->mat_param + 8 * i;
         out.mats.push_back(DMaterial{m[0], m[1], m[2], m[3], m[4], m[5], m[6], d->mat_pattern[i]});
     }
-    std::vector<DPrim> prims;  // by primitive index; moved into stream order below
+    std::vector<DPrim> prims;  // by primitive index
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         if (d->prim_type[i] > RT_PRIM_SMOOTH_TRIANGLE) {
             err = "unknown primitive tag";
@@ -100,42 +250,80 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         prims.push_back(p);
     }
     if (out.extras.empty()) out.extras.push_back(DExtra{});  // never hand a null table to the kernel
-    // Item tree: pre-order with forward skip links.  i < next <= n_items and proper nesting
-    // guarantee that every traversal (which only ever moves to i+1 or next[i]) terminates.
+
+    // The caller's item tree: pre-order with forward skip links.  i < next <= n_items and proper
+    // nesting are checked; Groups become gates, primitives remember their innermost Group.
+    std::vector<DPrim> item_rec(d->n_items);
+    std::vector<uint32_t> item_gate(d->n_items, kNoGate);
+    std::vector<uint32_t> prim_items;  // items that are primitives, in world.objects order
     {
-        std::vector<uint32_t> open;  // ends of the enclosing subtrees
+        std::vector<uint32_t> open_end, open_gate;  // enclosing subtrees: their ends and gates
         std::vector<uint8_t> prim_seen(d->n_prims, 0);
         for (uint32_t i = 0; i < d->n_items; ++i) {
-            while (!open.empty() && open.back() == i) open.pop_back();
-            uint32_t ref = d->item_ref[i], next = d->item_next[i];
+            while (!open_end.empty() && open_end.back() == i) open_end.pop_back(), open_gate.pop_back();
+            const uint32_t ref = d->item_ref[i], next = d->item_next[i];
             if (next <= i || next > d->n_items) return bad("item_next out of range");
-            if (!open.empty() && next > open.back()) return bad("item subtree crosses its parent's end");
+            if (!open_end.empty() && next > open_end.back()) return bad("item subtree crosses its parent's end");
+            const uint32_t enclosing = open_gate.empty() ? kNoGate : open_gate.back();
             if (ref & RT_ITEM_NODE) {
-                if ((ref & ~RT_ITEM_NODE) >= d->n_nodes) return bad("item node index out of range");
-                if (next > i + 1) open.push_back(next);
+                const uint32_t n = ref & ~RT_ITEM_NODE;
+                if (n >= d->n_nodes) return bad("item node index out of range");
+                DGate g{};
+                for (int k = 0; k < 3; ++k) {
+                    g.mn[k] = widen(d->node_min[3 * n + k], false);
+                    g.mx[k] = widen(d->node_max[3 * n + k], true);
+                }
+                g.parent = enclosing;
+                if (next > i + 1) {
+                    open_end.push_back(next);
+                    open_gate.push_back(static_cast<uint32_t>(out.gates.size()));
+                }
+                out.gates.push_back(g);
             } else {
                 if (ref >= d->n_prims) return bad("item primitive index out of range");
                 if (next != i + 1) return bad("a primitive item must link to the next item");
                 if (prim_seen[ref]) return bad("primitive referenced by more than one item");
                 prim_seen[ref] = 1;
-            }
-            if (ref & RT_ITEM_NODE) {
-                const uint32_t n = ref & ~RT_ITEM_NODE;
-                DPrim r{};
-                for (int k = 0; k < 3; ++k) {
-                    r.inv[k] = widen(d->node_min[3 * n + k], false);
-                    r.inv[3 + k] = widen(d->node_max[3 * n + k], true);
-                }
-                r.type = REC_NODE;
-                r.material = next;
-                out.recs.push_back(r);
-            } else {
-                out.recs.push_back(prims[ref]);
+                item_rec[i] = prims[ref];
+                item_gate[i] = enclosing;
+                prim_items.push_back(i);
+                out.exotic |= prims[ref].type >= PRIM_CYLINDER;
+                out.has_gates |= enclosing != kNoGate;
             }
         }
     }
-    out.n_items = d->n_items;
-    if (out.recs.empty()) out.recs.push_back(DPrim{});  // placeholder, n_items stays 0
+    if (out.gates.empty()) out.gates.push_back(DGate{});
+
+    // Lay the stream out.
+    auto emit_flat = [&](uint32_t item) {
+        out.recs.push_back(item_rec[item]);
+        out.order.push_back(item);
+        out.gate.push_back(item_gate[item]);
+    };
+    if (prim_items.size() <= kFlatLimit && !out.has_gates) {
+        for (uint32_t item : prim_items) emit_flat(item);
+    } else {
+        BvhBuild b;
+        b.out = &out, b.item_rec = &item_rec, b.item_gate = &item_gate;
+        for (uint32_t item : prim_items) {
+            const uint32_t ref = d->item_ref[item];
+            const HostBox box = prim_world_box(d->prim_type[ref], d->prim_inv + 12 * ref,
+                                               d->prim_param ? d->prim_param + 24 * ref : nullptr);
+            if (box.bounded) b.boxes.push_back(box), b.ids.push_back(item);
+            else emit_flat(item);  // unbounded primitives stay at the top, in order
+        }
+        if (b.ids.size() <= 2) {
+            for (uint32_t item : b.ids) emit_flat(item);
+        } else {
+            b.perm.resize(b.ids.size());
+            for (uint32_t k = 0; k < b.perm.size(); ++k) b.perm[k] = k;
+            b.build(0, static_cast<uint32_t>(b.perm.size()));
+            out.has_bvh = true;
+        }
+    }
+    out.n_items = static_cast<uint32_t>(out.recs.size());
+    if (out.recs.empty()) out.recs.push_back(DPrim{}), out.order.push_back(0), out.gate.push_back(kNoGate);
+
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         if (d->light_type[i] > RT_LIGHT_AREA) {
             err = "unknown light tag";

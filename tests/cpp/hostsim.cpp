@@ -31,27 +31,34 @@ struct Closest {
     float t, u, v;
 };
 
-// visit(i, record) -> keep going?   Records are walked in stream order; a node whose box the ray's
-// LINE misses is jumped over (its `next` link is kept in `material`).
-template <class Visit>
-void traverse(const Sim& s, const Ray& ray, Visit&& visit) {
+// visit(i, record) -> keep going?   Records are walked in stream order; a node of the device's
+// hierarchy whose box the ray cannot meet within [t_lo, t_hi()] is jumped over (its `next` link is
+// kept in `material`).  The caller's Groups are gates checked on a primitive's own hits.
+template <class THi, class Visit>
+void traverse(const Sim& s, const Ray& ray, float t_lo, THi&& t_hi, Visit&& visit) {
+    const V3 inv_d = inv_dir(ray.d);
     uint32_t i = 0;
     while (i < s.ps.n_items) {
         const DPrim& r = s.ps.recs[i];
         if (r.type == REC_NODE) {
-            i = node_hit(r, ray.o, ray.d) ? i + 1 : r.material;
+            i = bvh_node_hit(r, ray.o, inv_d, t_lo, t_hi()) ? i + 1 : r.material;
             continue;
         }
         if (!visit(i, r)) return;
         ++i;
     }
 }
+bool gated_in(const Sim& s, uint32_t prim, const Ray& ray) {
+    return !s.ps.has_gates || gates_pass(s.ps.gates.data(), s.ps.gate[prim], ray.o, ray.d);
+}
 
 Closest closest_hit(const Sim& s, const Ray& ray) {
     Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
-    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+    traverse(s, ray, 0.0f, [&] { return c.t + tie_window(c.t); }, [&](uint32_t prim, const DPrim& p) {
         intersect_prim(p, s.ps.extras.data(), ray, prim == ray.self, [&](int, float t, float u, float v) {
-            if (closer_hit(t, c.t)) c = Closest{prim, t, u, v};
+            bool better = closer_hit(t, c.t);
+            if (!better && c.prim != kNoPrim && ties_hit(t, c.t)) better = s.ps.order[prim] < s.ps.order[c.prim];
+            if (better && gated_in(s, prim, ray)) c = Closest{prim, t, u, v};
         });
         return true;
     });
@@ -61,11 +68,13 @@ Closest closest_hit(const Sim& s, const Ray& ray) {
 // world.rs:73-92: shadowed iff the nearest positive hit is closer than the light
 bool occluded(const Sim& s, const Ray& ray, float dist) {
     bool occ = false;
-    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+    traverse(s, ray, 0.0f, [&] { return dist; }, [&](uint32_t prim, const DPrim& p) {
+        bool hit = false;
         if (prim == ray.self)
-            intersect_prim(p, s.ps.extras.data(), ray, true, [&](int, float t, float, float) { occ |= in_range(t, dist); });
+            intersect_prim(p, s.ps.extras.data(), ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
         else
-            occ = occludes_prim(p, s.ps.extras.data(), ray.o, ray.d, dist);
+            hit = occludes_prim(p, s.ps.extras.data(), ray.o, ray.d, dist);
+        occ = hit && gated_in(s, prim, ray);
         return !occ;
     });
     return occ;
@@ -76,11 +85,12 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
 // crossing before the hit has the largest t.
 void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2) {
     ContainerScan cs;
-    traverse(s, ray, [&](uint32_t prim, const DPrim& p) {
+    traverse(s, ray, -INFINITY, [&] { return INFINITY; }, [&](uint32_t prim, const DPrim& p) {
         Hits h;
         h.t[0] = h.t[1] = h.t[2] = h.t[3] = RT_NOHIT;
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot] = t; });
-        cs.add(h, prim, p.ior, hit_prim, t_hit);
+        bool any = false;
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot] = t, any = true; });
+        if (any && gated_in(s, prim, ray)) cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit);
         return true;
     });
     cs.finish(hit_ior, n1, n2);
