@@ -280,11 +280,14 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
+                if (has_hit) phong_cell(lp, over, nrm, eye, m_shininess, sum_d, sum_s);
+                // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
+                // ray cannot change the pixel and is answered without tracing
+                const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = hq, sr.dq = hdq;
-                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast);
+                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters);
                 lit = occ ? 0.0f : 1.0f;
-                if (has_hit) phong_cell(lp, over, nrm, eye, m_shininess, sum_d, sum_s);
                 if (STATS && cast) c_shadow++;
                 if (STATS && has_hit) c_cells++;
             } else {
@@ -319,6 +322,13 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                         sum_d += ldn, sum_s += spec;
                     }
                     if (STATS && has_hit) c_cells += cells;
+                    // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums
+                    // are exactly zero and multiply the intensity (material.rs:161), so the shadow rays
+                    // of this point cannot change the pixel.  They still count as rays of the
+                    // reference's accounting (light.rs:196-208 casts them), answered without tracing.
+                    const bool dark = has_hit && sum_d == 0.0f && sum_s == 0.0f;
+                    if (STATS && dark) c_shadow += cells;
+                    need &= ~__ballot(dark);
                 }
 
                 while (need) {
