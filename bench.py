@@ -89,6 +89,19 @@ def cpu_baseline(name: str, width: int, height: int, jitter: int, seed: int, tar
     }, st
 
 
+def traffic_from_profile(args, world):
+    """HBM bytes per launch of the render kernel, measured with PMC counters in their own runs
+    (scripts/traffic.sh) and committed as profiles/traffic.json — valid for the default workload on
+    one GPU only; anything else reports null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    default = args.workload == "striped_sphere_multiple_lights" and not args.width and not args.height and \
+        args.jitter == "counter" and args.seed == 0
+    if world != 1 or not default or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,9 +217,9 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved, "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / flopmodel.PEAK_FP32_TFLOPS,
-                # HBM bytes per launch: PMC passes are separate runs (scripts/pmc.sh); the committed
-                # summary under profiles/ holds FETCH_SIZE/WRITE_SIZE (≈ the framebuffer write)
-                "traffic": None,
+                # HBM bytes per launch come from SEPARATE rocprofv3 --pmc runs of this same command
+                # (scripts/traffic.sh -> profiles/traffic.json, default workload only); null otherwise
+                "traffic": traffic_from_profile(args, world),
                 "algorithmic_hbm_bytes_per_launch": int(scene.output_rows(ex.camera_desc, opt)) * width * 12,
                 "algorithmic_flop_per_launch": flops, "flop_per_ray_intersection": cost,
                 "kernel": "render_kernel<false, false, false>", "kernel_ms": kernel_ms,

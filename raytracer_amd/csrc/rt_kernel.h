@@ -70,7 +70,9 @@ struct KParams {
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
 
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// the builtin keeps the predicate as a lane mask (s_and with exec); __ballot() goes through a VGPR
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return wave_ballot(p) != 0ull; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ uint32_t shfl_u(uint32_t v, int src) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), src, 64)); }
@@ -139,7 +141,11 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
             if (decltype(self)::value)
                 intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
             else
+#if RT_EXP & 16
+                hit = p.type == PRIM_SPHERE ? false : occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
+#else
                 hit = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
+#endif
             if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
             occ = hit;
             return !occ;
@@ -189,6 +195,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
 
     StackEntry stack[kStackCap];
     int sp = 0;
+    __shared__ float s_park[24 * 256];
+    float* const park = s_park + threadIdx.x;
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
                        c_cells = 0, c_pattern = 0, c_container = 0;
@@ -259,7 +267,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             }
         }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
-        const V3 eye = neg(cur.d);
+        // normal, eye vector and shininess are only needed by the Phong sums: parked as well
+        auto ld3 = [&](int k) { return v3(park[k * 256], park[(k + 1) * 256], park[(k + 2) * 256]); };
+        park[17 * 256] = nrm.x, park[18 * 256] = nrm.y, park[19 * 256] = nrm.z;
+        park[20 * 256] = -cur.d.x, park[21 * 256] = -cur.d.y, park[22 * 256] = -cur.d.z;
 
         // ---------------------------------------------------------------- shade (world.rs:43-58)
         float m_ambient = 0.0f, m_diffuse = 0.0f, m_specular = 0.0f, m_shininess = 1.0f;
@@ -267,7 +278,16 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             const DMaterial m = sc.mats[mi];
             m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
         }
-        V3 surface = v3(0.0f, 0.0f, 0.0f);
+        park[23 * 256] = m_shininess;
+        // What the light loops do not touch waits in LDS (slot k of this lane at park[k * 256]): the
+        // shading loops need every register they can get at 4 waves/SIMD, and a value parked here
+        // costs no memory traffic, unlike a compiler spill to scratch.
+        park[0 * 256] = w.x, park[1 * 256] = w.y, park[2 * 256] = w.z;
+        park[3 * 256] = acc.x, park[4 * 256] = acc.y, park[5 * 256] = acc.z;
+        park[6 * 256] = n1, park[7 * 256] = n2;
+        park[8 * 256] = pc.x, park[9 * 256] = pc.y, park[10 * 256] = pc.z;
+        park[11 * 256] = m_ambient, park[12 * 256] = m_diffuse, park[13 * 256] = m_specular;
+        park[14 * 256] = 0.0f, park[15 * 256] = 0.0f, park[16 * 256] = 0.0f;  // surface colour so far
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             const DLight l = sc.lights[li];
             const V3 lc = v3(l.color[0], l.color[1], l.color[2]);
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
-                if (has_hit) phong_cell(lp, over, nrm, eye, m_shininess, sum_d, sum_s);
+                if (has_hit) phong_cell(lp, over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
                 // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
                 // ray cannot change the pixel and is answered without tracing
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
@@ -309,6 +329,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 // (chunk 0) and is broadcast with v_readlane; summed in cell order.
                 const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
                 if (local_phong && !(RT_EXP & 2)) {
+                    const V3 p_n = ld3(17), p_eye = ld3(20);
+                    const float p_shin = park[23 * 256];
                     for (uint32_t c = 0; c < cells; ++c) {
                         V3 centre;
                         if (c < 64u) {
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                             centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
                         }
                         float ldn = 0.0f, spec = 0.0f;
-                        if (has_hit) phong_cell(centre, over, nrm, eye, m_shininess, ldn, spec);
+                        if (has_hit) phong_cell(centre, over, p_n, p_eye, p_shin, ldn, spec);
                         sum_d += ldn, sum_s += spec;
                     }
                     if (STATS && has_hit) c_cells += cells;
@@ -352,11 +374,11 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                         const int os = __builtin_amdgcn_readfirstlane(owner);
                         sr.o = rl_v3(over, os), sr.self = rl_u(hit_prim, os), sr.q = rl_v3(hq, os), sr.dq = rl_v3(hdq, os);
                         o_key = rl_u(pixel_key, os), o_node = rl_u(node, os);
-                        if (!local_phong) o_n = rl_v3(nrm, os), o_eye = rl_v3(eye, os), o_shin = rl_f(m_shininess, os);
+                        if (!local_phong) o_n = rl_v3(ld3(17), os), o_eye = rl_v3(ld3(20), os), o_shin = rl_f(park[23 * 256], os);
                     } else {
                         sr.o = shfl_v3(over, owner), sr.self = shfl_u(hit_prim, owner), sr.q = shfl_v3(hq, owner), sr.dq = shfl_v3(hdq, owner);
                         o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner);
-                        if (!local_phong) o_n = shfl_v3(nrm, owner), o_eye = shfl_v3(eye, owner), o_shin = shfl_f(m_shininess, owner);
+                        if (!local_phong) o_n = shfl_v3(ld3(17), owner), o_eye = shfl_v3(ld3(20), owner), o_shin = shfl_f(park[23 * 256], owner);
                     }
                     unsigned int my_lit = 0;
                     float my_d = 0.0f, my_s = 0.0f;
@@ -410,12 +432,18 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 lit *= l.inv_samples;  // light.rs:208
             }
             if (has_hit) {  // material.rs:127-161
-                const V3 ec = pc * lc;
-                const V3 shade = ec * (m_diffuse * sum_d) + lc * (m_specular * sum_s);
-                surface = surface + ec * m_ambient + shade * (l.inv_samples * lit);
+                const V3 ec = v3(park[8 * 256], park[9 * 256], park[10 * 256]) * lc;
+                const V3 shade = ec * (park[12 * 256] * sum_d) + lc * (park[13 * 256] * sum_s);
+                const V3 add = ec * park[11 * 256] + shade * (l.inv_samples * lit);
+                park[14 * 256] += add.x, park[15 * 256] += add.y, park[16 * 256] += add.z;
             }
         }
-        if (has_hit) acc = acc + w * surface;
+        w = v3(park[0 * 256], park[1 * 256], park[2 * 256]);
+        acc = v3(park[3 * 256], park[4 * 256], park[5 * 256]);
+        n1 = park[6 * 256], n2 = park[7 * 256];
+        nrm = ld3(17);
+        const V3 eye = ld3(20);
+        if (has_hit) acc = acc + w * v3(park[14 * 256], park[15 * 256], park[16 * 256]);
 
         // ---------------------------------------------------------------- children (world.rs:59-69,94-133)
         float m_reflectivity = 0.0f, m_transparency = 0.0f;
