@@ -270,8 +270,10 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
                 if (n >= d->n_nodes) return bad("item node index out of range");
                 DGate g{};
                 for (int k = 0; k < 3; ++k) {
-                    g.mn[k] = widen(d->node_min[3 * n + k], false);
-                    g.mx[k] = widen(d->node_max[3 * n + k], true);
+                    g.mn[k] = d->node_min[3 * n + k], g.mx[k] = d->node_max[3 * n + k];
+                    // a box of zero thickness is never entered (tmin < tmax is strict):
+                    // that quirk is part of the reference's output, so such an axis is not widened
+                    if (g.mn[k] != g.mx[k]) g.mn[k] = widen(g.mn[k], false), g.mx[k] = widen(g.mx[k], true);
                 }
                 g.parent = enclosing;
                 if (next > i + 1) {

@@ -201,6 +201,31 @@ def test_edge_cases():
     assert L.rt_scene_create(ex.scene_desc, 99, C.byref(out)) == -1
 
 
+@pytest.mark.parametrize("box", [([-2000, -2000, -2000], [2000, 2000, 2000]),  # encloses everything
+                                 ([-2000, 0.5, -2000], [2000, 0.5, 2000]),      # zero thickness: never entered
+                                 ([5000, 5000, 5000], [5001, 5001, 5001])])     # elsewhere
+def test_group_gates_on_the_device(box):
+    """group.rs:106-119 on the kernel: a Group's box decides whether its children exist for a ray,
+    although the device walks its own hierarchy (tests/test_groups_and_hierarchy.py has the CPU side)."""
+    from test_groups_and_hierarchy import Wrapped, grouped_desc, truncated
+
+    ex = ExampleScene("cover_image", 64, 36)
+    keep = []
+    d = grouped_desc(ex, 2, box[0], box[1], keep)
+    sc = Scene(C.pointer(d), 0)
+    gpu, _ = sc.render(ex.camera_desc)
+    sc.close()
+    hidden = box[0][1] == box[1][1] or box[0][0] > 1000
+    dref = truncated(ex, 2)
+    sc = Scene(C.pointer(dref) if hidden else ex.scene_desc, 0)  # hidden children == absent children
+    ref, _ = sc.render(ex.camera_desc)
+    sc.close()
+    assert np.array_equal(gpu, ref)
+    sim = H.hostsim_render(Wrapped(ex, d), RtOptions())
+    dd = np.abs(gpu - sim).max(axis=-1)
+    assert np.median(dd) <= 1e-6 and (dd > 1e-5).mean() <= 2e-3
+
+
 def test_stochastic_scene_against_independent_jitter():
     """North-star bar for area-light scenes: RMSE against a render with INDEPENDENT jitter at the same
     sample count is within 1.1x the noise floor between two such independent renders."""
