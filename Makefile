@@ -15,8 +15,8 @@ $(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kern
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) raytracer_amd/csrc/rt_amd.hip -o $@
 
-$(LIBDIR)/librt_scenes.so: scenes/scenes_capi.cpp scenes/examples.inc include/raytracer_amd/raytracer.hpp include/rt_amd.h $(LIBDIR)/librt_amd.so
-	$(CXX) $(CXXFLAGS) -shared scenes/scenes_capi.cpp -o $@ -L$(LIBDIR) -lrt_amd -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/librt_scenes.so: scenes/scenes_capi.cpp scenes/examples.inc include/raytracer_amd/raytracer.hpp include/raytracer_amd/png.hpp include/rt_amd.h $(LIBDIR)/librt_amd.so
+	$(CXX) $(CXXFLAGS) -shared scenes/scenes_capi.cpp -o $@ -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

@@ -45,6 +45,7 @@ WORKLOADS = {  # BASELINE.json configs (the scene files as written; SURVEY.md §
     "cover_image": (3840, 2160),
     "cover_image_area": (3840, 2160),
     "shapes_zoo": (1920, 1080),
+    "obj_mesh": (1920, 1080),
 }
 BAND_ROWS = partition.BAND_ROWS
 

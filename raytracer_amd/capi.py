@@ -130,6 +130,8 @@ def scenes_lib() -> C.CDLL:
         S.rtx_render_example.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(RtOptions), C.c_int, C.c_void_p,
                                          C.POINTER(RtStats)]
         S.rtx_scene_name.restype = C.c_char_p
+        S.rtx_render_example_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(RtOptions), C.c_int, C.c_char_p]
+        S.rtx_png_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _scenes = S
     return _scenes
 

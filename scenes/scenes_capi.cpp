@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <string>
 
+#include "../include/raytracer_amd/png.hpp"
 #include "../include/raytracer_amd/raytracer.hpp"
 
 #define RT_API_NS rt
@@ -57,6 +58,43 @@ int rtx_render_example(const char* name, int width, int height, const rt_options
         }
         rt::Canvas canvas = scene.camera.render(scene.world, options, device, stats);
         std::copy(canvas.rgb.begin(), canvas.rgb.end(), rgb);
+        return RT_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RT_ERR_BAD_ARGUMENT;
+    }
+}
+
+// `canvas.to_image().save(path)` of examples/*.rs: render, quantise on the device, write a PNG.
+int rtx_render_example_png(const char* name, int width, int height, const rt_options* options, int device, const char* path) {
+    try {
+        rt::Scene scene;
+        if (!name || !path || !rt::examples::build(name, static_cast<size_t>(width), static_cast<size_t>(height), scene)) {
+            g_err = std::string("unknown scene: ") + (name ? name : "(null)");
+            return RT_ERR_BAD_ARGUMENT;
+        }
+        const rt::Canvas canvas = scene.camera.render(scene.world, options, device, nullptr);
+        const std::vector<uint8_t> bytes = canvas.to_image();
+        rt::save_png(path, bytes.data(), canvas.width, canvas.height);
+        return RT_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RT_ERR_BAD_ARGUMENT;
+    }
+}
+
+// PNG encoder alone (host only): out may be null to query the size.
+int rtx_png_encode(const uint8_t* rgb, int width, int height, uint8_t* out, size_t cap, size_t* len) {
+    try {
+        const std::vector<uint8_t> png = rt::encode_png(rgb, static_cast<size_t>(width), static_cast<size_t>(height));
+        if (len) *len = png.size();
+        if (out) {
+            if (cap < png.size()) {
+                g_err = "output buffer too small";
+                return RT_ERR_CAPACITY;
+            }
+            std::copy(png.begin(), png.end(), out);
+        }
         return RT_OK;
     } catch (const std::exception& e) {
         g_err = e.what();

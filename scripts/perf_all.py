@@ -23,7 +23,7 @@ from raytracer_amd import ExampleScene, RtOptions, Scene, flopmodel  # noqa: E40
 FULL = {
     "checkered_walls_metallic_sphere": (1280, 720), "striped_sphere_multiple_lights": (1920, 1080),
     "glass_sphere_checkered_floor_aerial_view": (1920, 1080), "multiple_glass_and_metallic_spheres": (3840, 2160),
-    "cover_image": (3840, 2160), "cover_image_area": (3840, 2160), "shapes_zoo": (1920, 1080),
+    "cover_image": (3840, 2160), "cover_image_area": (3840, 2160), "shapes_zoo": (1920, 1080), "obj_mesh": (1920, 1080),
 }
 
 

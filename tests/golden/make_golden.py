@@ -36,6 +36,7 @@ FULL = {  # BASELINE.json configs
     "cover_image": (3840, 2160),
     "cover_image_area": (3840, 2160),
     "shapes_zoo": (1920, 1080),
+    "obj_mesh": (1920, 1080),
 }
 AREA_SCENES = ["checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
                "glass_sphere_checkered_floor_aerial_view", "cover_image_area", "shapes_zoo"]

@@ -22,7 +22,7 @@ JITTER_CENTER, JITTER_COUNTER, JITTER_THREAD_RNG = 0, 1, 2
 SCENES = [
     "test_world", "checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
     "glass_sphere_checkered_floor_aerial_view", "multiple_glass_and_metallic_spheres",
-    "cover_image", "cover_image_area", "shapes_zoo",
+    "cover_image", "cover_image_area", "shapes_zoo", "obj_mesh",
 ]
 
 _oracle = None

@@ -30,6 +30,7 @@ BAD_FRAC = {
     "cover_image": 1e-3,
     "cover_image_area": 1e-3,
     "shapes_zoo": 2e-2,  # ring pattern aliasing at the horizon rows
+    "obj_mesh": 2e-3,  # 584 OBJ triangles (smooth + flat) through the loader
 }
 
 

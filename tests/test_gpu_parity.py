@@ -21,12 +21,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BAD_FRAC = {  # same limits as tests/test_fp32_math_cpu.py (96x54 images)
     "test_world": 0.0, "checkered_walls_metallic_sphere": 2e-3, "striped_sphere_multiple_lights": 2e-3,
     "glass_sphere_checkered_floor_aerial_view": 4e-3, "multiple_glass_and_metallic_spheres": 4e-3,
-    "cover_image": 1e-3, "cover_image_area": 1e-3, "shapes_zoo": 2e-2,
+    "cover_image": 1e-3, "cover_image_area": 1e-3, "shapes_zoo": 2e-2, "obj_mesh": 2e-3,
 }
 FULL = {
     "checkered_walls_metallic_sphere": (1280, 720), "striped_sphere_multiple_lights": (1920, 1080),
     "glass_sphere_checkered_floor_aerial_view": (1920, 1080), "multiple_glass_and_metallic_spheres": (3840, 2160),
-    "cover_image": (3840, 2160), "cover_image_area": (3840, 2160), "shapes_zoo": (1920, 1080),
+    "cover_image": (3840, 2160), "cover_image_area": (3840, 2160), "shapes_zoo": (1920, 1080), "obj_mesh": (1920, 1080),
 }
 
 
