@@ -1,0 +1,129 @@
+//! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 1).  What `bindgen` would emit, written
+//! by hand because the header is small and stable.  UNVERIFIED: no Rust toolchain exists in the
+//! environment this was written in; the C++ mirror of the same calls is what is compiled and tested.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const RT_ABI_VERSION: u32 = 1;
+pub const RT_ITEM_NODE: u32 = 0x8000_0000;
+pub const RT_OK: c_int = 0;
+
+pub const RT_PRIM_SPHERE: u8 = 0;
+pub const RT_PRIM_PLANE: u8 = 1;
+pub const RT_PRIM_CUBE: u8 = 2;
+pub const RT_PRIM_CYLINDER: u8 = 3;
+pub const RT_PRIM_TRIANGLE: u8 = 4;
+pub const RT_PRIM_SMOOTH_TRIANGLE: u8 = 5;
+pub const RT_PAT_SOLID: u8 = 0;
+pub const RT_PAT_STRIPE: u8 = 1;
+pub const RT_PAT_GRADIENT: u8 = 2;
+pub const RT_PAT_RING: u8 = 3;
+pub const RT_PAT_CHECKER: u8 = 4;
+pub const RT_LIGHT_POINT: u8 = 0;
+pub const RT_LIGHT_AREA: u8 = 1;
+pub const RT_JITTER_CENTER: u32 = 0;
+pub const RT_JITTER_COUNTER: u32 = 1;
+
+#[repr(C)]
+pub struct rt_scene_desc {
+    pub abi_version: u32,
+    pub n_prims: u32,
+    pub prim_type: *const u8,
+    pub prim_inv: *const f32,
+    pub prim_material: *const u32,
+    pub prim_param: *const f32,
+    pub n_nodes: u32,
+    pub node_min: *const f32,
+    pub node_max: *const f32,
+    pub n_items: u32,
+    pub item_ref: *const u32,
+    pub item_next: *const u32,
+    pub n_materials: u32,
+    pub mat_param: *const f32,
+    pub mat_pattern: *const u32,
+    pub n_patterns: u32,
+    pub pat_type: *const u8,
+    pub pat_color_a: *const f32,
+    pub pat_color_b: *const f32,
+    pub pat_inv: *const f32,
+    pub n_lights: u32,
+    pub light_type: *const u8,
+    pub light_pos: *const f32,
+    pub light_uvec: *const f32,
+    pub light_vvec: *const f32,
+    pub light_usteps: *const u32,
+    pub light_vsteps: *const u32,
+    pub light_color: *const f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_camera_desc {
+    pub hsize: u32,
+    pub vsize: u32,
+    pub pixel_size: f32,
+    pub half_width: f32,
+    pub half_height: f32,
+    pub inv: [f32; 12],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_options {
+    pub max_depth: u32,
+    pub jitter_mode: u32,
+    pub seed: u32,
+    pub tile_rows: u32,
+    pub tile_first: u32,
+    pub tile_stride: u32,
+    pub flags: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_stats {
+    pub primary_rays: u64,
+    pub reflection_rays: u64,
+    pub refraction_rays: u64,
+    pub shadow_rays: u64,
+    pub shaded_hits: u64,
+    pub light_cells: u64,
+    pub pattern_lookups: u64,
+    pub container_passes: u64,
+    pub pixels: u64,
+    pub kernel_ms: f32,
+}
+
+pub enum rt_scene {}
+
+extern "C" {
+    pub fn rt_abi_version() -> u32;
+    pub fn rt_last_error() -> *const c_char;
+    pub fn rt_device_count(count_out: *mut c_int) -> c_int;
+    pub fn rt_scene_create(desc: *const rt_scene_desc, device: c_int, scene_out: *mut *mut rt_scene) -> c_int;
+    pub fn rt_scene_destroy(scene: *mut rt_scene);
+    pub fn rt_output_rows(camera: *const rt_camera_desc, options: *const rt_options, rows_out: *mut u32) -> c_int;
+    pub fn rt_render_device(
+        scene: *mut rt_scene,
+        camera: *const rt_camera_desc,
+        options: *const rt_options,
+        rgb_out_device: *mut f32,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn rt_render(
+        scene: *mut rt_scene,
+        camera: *const rt_camera_desc,
+        options: *const rt_options,
+        rgb_out_host: *mut f32,
+        stats_out: *mut rt_stats,
+    ) -> c_int;
+    pub fn rt_render_stats(
+        scene: *mut rt_scene,
+        camera: *const rt_camera_desc,
+        options: *const rt_options,
+        rgb_out_host: *mut f32,
+        stats_out: *mut rt_stats,
+    ) -> c_int;
+    pub fn rt_quantize_u8_device(rgb_device: *const f32, n: usize, out_device: *mut u8, device: c_int, stream: *mut c_void) -> c_int;
+    pub fn rt_quantize_u8(rgb_host: *const f32, n: usize, out_host: *mut u8) -> c_int;
+}
