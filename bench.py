@@ -223,7 +223,7 @@ def main():
                 "traffic": traffic_from_profile(args, world),
                 "algorithmic_hbm_bytes_per_launch": int(scene.output_rows(ex.camera_desc, opt)) * width * 12,
                 "algorithmic_flop_per_launch": flops, "flop_per_ray_intersection": cost,
-                "kernel": "render_kernel<false, false, false>", "kernel_ms": kernel_ms,
+                "kernel": "render_kernel<false, false, false, true>", "kernel_ms": kernel_ms,
             },
         }
         if base is not None:

@@ -83,6 +83,7 @@ struct rt_scene {
     int device = 0;
     bool exotic = false;  // some primitive is a cylinder or a triangle
     bool tree = false;    // the stream has hierarchy nodes or Group gates
+    bool area = false;    // some light is an area light
     KScene k{};
     std::vector<void*> owned;
     unsigned long long* counters = nullptr;
@@ -108,13 +109,18 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.n_tiles = P.tiles_x * tiles_y;
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t blocks = (P.n_tiles + 3u) / 4u;  // 4 waves (tiles) per 256-thread block
-    // eight instantiations: counters x cylinder/triangle code x hierarchy/gate code
+    // sixteen instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code
     if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
-    const int variant = (stats ? 4 : 0) | (s->exotic ? 2 : 0) | (s->tree ? 1 : 0);
-    void (*kernels[8])(const KParams) = {render_kernel<false, false, false>, render_kernel<false, false, true>,
-                                         render_kernel<false, true, false>,  render_kernel<false, true, true>,
-                                         render_kernel<true, false, false>,  render_kernel<true, false, true>,
-                                         render_kernel<true, true, false>,   render_kernel<true, true, true>};
+    const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
+    void (*kernels[16])(const KParams) = {
+        render_kernel<false, false, false, false>, render_kernel<false, false, false, true>,
+        render_kernel<false, false, true, false>,  render_kernel<false, false, true, true>,
+        render_kernel<false, true, false, false>,  render_kernel<false, true, false, true>,
+        render_kernel<false, true, true, false>,   render_kernel<false, true, true, true>,
+        render_kernel<true, false, false, false>,  render_kernel<true, false, false, true>,
+        render_kernel<true, false, true, false>,   render_kernel<true, false, true, true>,
+        render_kernel<true, true, false, false>,   render_kernel<true, true, false, true>,
+        render_kernel<true, true, true, false>,    render_kernel<true, true, true, true>};
     hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(256), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -196,6 +202,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     rc = upload(ps.recs, &s->k.recs, s->owned);
     if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
     if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
+    if (rc == RT_OK) rc = upload(ps.bound, &s->k.bound, s->owned);
     if (rc == RT_OK) rc = upload(ps.gates, &s->k.gates, s->owned);
     if (rc == RT_OK) rc = upload(ps.extras, &s->k.extras, s->owned);
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
@@ -205,6 +212,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     s->k.has_gates = ps.has_gates, s->k.has_bvh = ps.has_bvh;
     s->exotic = ps.exotic;
     s->tree = ps.has_bvh || ps.has_gates;
+    s->area = ps.has_area;
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {
         void* c = nullptr;

@@ -50,6 +50,7 @@ struct KScene {
     const DPrim* recs;      // the traversal stream (rt_math.h, rt_pack.h)
     const uint32_t* order;  // per record: world.objects position of the primitive (tie order)
     const uint32_t* gate;   // per record: innermost enclosing Group of the caller's tree, or kNoGate
+    const DBound* bound;    // per record: world-space bounding ball (shaft tests)
     const DGate* gates;
     const DExtra* extras;
     const DMaterial* mats;
@@ -92,10 +93,25 @@ __device__ __forceinline__ V3 rl_v3(V3 v, int src) { return V3{rl_f(v.x, src), r
 // so the two variants of the intersection code almost never run in the same iteration.  With 4
 // waves per SIMD the load latency is covered by the other waves; requesting record i+1 ahead
 // (RT_PREFETCH) measured slower because of the 16 SGPR copies per record.
+// Flat streams (TREE = false) take a wave-uniform `mask`: record i is visited only if bit min(i, 31)
+// is set (the shaft tests of the area-light pass clear the bits of records that cannot block).
 template <bool TREE, class Enter, class Visit>
-__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
+__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, uint32_t mask, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
+    if (!TREE) {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!((mask >> (i < 31u ? i : 31u)) & 1u)) continue;
+            if (!wave_any(live)) break;
+            const DPrim rec = sc.recs[i];
+            const bool on_self = live && i == self_prim;
+            if (wave_any(on_self)) {
+                if (on_self) live = visit(i, rec, std::true_type{});
+            }
+            if (live && !on_self) live = visit(i, rec, std::false_type{});
+        }
+        return;
+    }
     uint32_t i = 0;
     uint32_t skip = 0;  // per lane: sit out records below this index (a node whose box it missed)
     DPrim rec = sc.recs[0];
@@ -108,7 +124,7 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
         const bool part = live && i >= skip;
         uint32_t to = seq;
         if (TREE && rec.type == REC_NODE) {
-            const bool enter = part && enter_node(rec);
+            const bool enter = part && enter_node(i, rec);
             if (part && !enter) skip = rec.material;
             if (!wave_any(enter)) to = rec.material;
         } else {
@@ -130,12 +146,12 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 template <bool EXOTIC, bool TREE>
-__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live) {
+__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, uint32_t mask) {
     bool occ = false;
     V3 inv_d = v3(0.0f, 0.0f, 0.0f);
     if ((TREE && sc.has_bvh)) inv_d = inv_dir(ray.d);
     traverse<TREE>(
-        sc, ray.self, live, [&](const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); },
+        sc, ray.self, live, mask, [&](uint32_t, const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); },
         [&](uint32_t prim, const DPrim& p, auto self) {
             bool hit = false;
             if (decltype(self)::value)
@@ -165,7 +181,7 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // (profiles/r01_occupancy_sweep.txt); 5 and more spill too much.
 // EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
 // hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
-template <bool STATS, bool EXOTIC, bool TREE>
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
 __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -208,8 +224,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if ((TREE && sc.has_bvh)) inv_d = inv_dir(cur.d);
         traverse<TREE>(
-            sc, cur.self, active,
-            [&](const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); },
+            sc, cur.self, active, ~0u,
+            [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); },
             [&](uint32_t prim, const DPrim& p, auto self) {
                 intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
                     // intersection.rs:105-120: smallest t > 0, world.objects order among approximately equal ones
@@ -230,14 +246,14 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
         V3 pc = v3(0.0f, 0.0f, 0.0f);
         uint32_t mi = 0;
         float n1 = 1.0f, n2 = 1.0f;
-        bool need_n = false;
+        bool need_n = false, hit_inside = false;
         float m_ior = 1.0f;
         if (has_hit) {
             const DPrim p = sc.recs[hit_prim];
             mi = p.material;
             const DMaterial m = sc.mats[mi];
             const HitInfo h = prepare_hit<EXOTIC>(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
-            over = h.p + h.n * kEps, nrm = h.n, hq = h.q, hdq = h.dq;
+            over = h.p + h.n * kEps, nrm = h.n, hq = h.q, hdq = h.dq, hit_inside = h.inside;
             pc = pattern_color(sc.pats[m.pattern], h.q + h.dq);  // pattern at over_point (material.rs:127)
             need_n = depth > 0u && m.transparency > 0.0f;
             m_ior = m.ior;
@@ -250,8 +266,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             ContainerScan cs;
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             traverse<TREE>(
-                sc, cur.self, need_n,
-                [&](const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, INFINITY); },  // every crossing counts
+                sc, cur.self, need_n, ~0u,
+                [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, INFINITY); },  // every crossing counts
                 [&](uint32_t prim, const DPrim& p, auto self) {
                     Hits hh;
                     hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
@@ -279,6 +295,9 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
         }
         park[23 * 256] = m_shininess;
+        // material.rs:146-159: diffuse and specular are products with these two coefficients; when both
+        // are zero no light sample and no shadow ray can change the pixel (ambient only)
+        const bool shades = has_hit && (m_diffuse != 0.0f || m_specular != 0.0f);
         // What the light loops do not touch waits in LDS (slot k of this lane at park[k * 256]): the
         // shading loops need every register they can get at 4 waves/SIMD, and a value parked here
         // costs no memory traffic, unlike a compiler spill to scratch.
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
             const DLight l = sc.lights[li];
             const V3 lc = v3(l.color[0], l.color[1], l.color[2]);
             float lit = 0.0f, sum_d = 0.0f, sum_s = 0.0f;
-            if (l.type == RT_LIGHT_POINT) {
+            if (!AREA || l.type == RT_LIGHT_POINT) {
                 // light.rs:182-188 + material.rs:138-159 with a single cell
                 const V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
                 const V3 tl = lp - over;
@@ -300,13 +319,13 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
-                if (has_hit) phong_cell(lp, over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
+                if (shades) phong_cell(lp, over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
                 // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
                 // ray cannot change the pixel and is answered without tracing
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = hq, sr.dq = hdq;
-                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters);
+                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters, ~0u);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && has_hit) c_cells++;
@@ -322,7 +341,42 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                 // this lane's cell of chunk 0 and its centre do not depend on the shading point
                 const uint32_t cv0 = sub / l.usteps, cu0 = sub - cv0 * l.usteps;
                 const V3 centre0 = point_on_light(l, cu0, cv0, 0.5f, 0.5f);
-                unsigned long long need = __ballot(has_hit);
+                unsigned long long need = __ballot(shades);
+                if (STATS && has_hit && !shades) c_shadow += cells, c_cells += cells;  // the reference casts them all the same
+
+                // Shaft tests (rt_math.h): which records could occlude ANY ray from this lane's point
+                // to this light, whatever the jitter.  Flat stream: one bit per record; hierarchy:
+                // nonzero = something might.  A point with none is fully lit without casting.
+                uint32_t blockers = shades ? ~0u : 0u;
+                if (!(RT_EXP & 32) && wave_any(shades)) {
+                    V3 lcen;
+                    float lrad;
+                    light_ball(l, lcen, lrad);
+                    const Shaft sh = make_shaft(over, lcen, lrad);
+                    const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
+                    blockers = 0u;
+                    traverse<TREE>(
+                        sc, hit_prim, shades, ~0u,
+                        [&](uint32_t i, const DPrim&) {
+                            const DBound b = sc.bound[i];
+                            return shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+                        },
+                        [&](uint32_t prim, const DPrim& p, auto self) {
+                            bool mb;
+                            if (decltype(self)::value) {
+                                mb = p.type >= PRIM_CYLINDER || !self_clear;  // convex shapes only
+                            } else if (p.type == PRIM_PLANE) {
+                                mb = shaft_meets_plane(sh, p.inv, fmaf(p.inv[4], over.x, fmaf(p.inv[5], over.y, fmaf(p.inv[6], over.z, p.inv[7]))));
+                            } else {
+                                const DBound b = sc.bound[prim];
+                                mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+                            }
+                            if (mb) blockers |= TREE ? 1u : (1u << (prim < 31u ? prim : 31u));
+                            return !(TREE && mb);
+                        });
+                }
+                const bool open = shades && blockers == 0u;
+                if (open) lit = static_cast<float>(cells);
 
                 // Phong sums over the cell centres.  Lane-local when at least half of the lanes'
                 // worth of cooperative passes would be needed: cell c's centre sits in lane c
@@ -340,44 +394,46 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
                             centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
                         }
                         float ldn = 0.0f, spec = 0.0f;
-                        if (has_hit) phong_cell(centre, over, p_n, p_eye, p_shin, ldn, spec);
+                        if (shades) phong_cell(centre, over, p_n, p_eye, p_shin, ldn, spec);
                         sum_d += ldn, sum_s += spec;
                     }
-                    if (STATS && has_hit) c_cells += cells;
+                    if (STATS && shades) c_cells += cells;
                     // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums
                     // are exactly zero and multiply the intensity (material.rs:161), so the shadow rays
                     // of this point cannot change the pixel.  They still count as rays of the
                     // reference's accounting (light.rs:196-208 casts them), answered without tracing.
-                    const bool dark = has_hit && sum_d == 0.0f && sum_s == 0.0f;
-                    if (STATS && dark) c_shadow += cells;
-                    need &= ~__ballot(dark);
+                    const bool dark = shades && sum_d == 0.0f && sum_s == 0.0f;
+                    // likewise the rays of a point whose shaft to the light is empty (`open`)
+                    if (STATS && (dark || open)) c_shadow += cells;
+                    need &= ~__ballot(dark || open);
                 }
 
                 while (need) {
                     // the shading points ("owners") of this pass: one per slot of g lanes
                     int owner = 0;
-                    uint32_t my_slot = 0, taken = 0;
+                    uint32_t my_slot = 0, taken = 0, pass_mask = 0;
                     bool owner_now = false;
                     for (uint32_t k = 0; k < slots && need; ++k) {
                         const int o = __ffsll(static_cast<long long>(need)) - 1;
                         need &= need - 1ull;
+                        pass_mask |= rl_u(blockers, o);
                         if (slot == k) owner = o;
                         if (static_cast<int>(lane) == o) my_slot = k, owner_now = true;
                         taken = k + 1;
                     }
                     const bool lane_on = slot < taken;
                     Ray sr;
-                    uint32_t o_key, o_node;
+                    uint32_t o_key, o_node, o_block;
                     V3 o_n = v3(0.0f, 0.0f, 0.0f), o_eye = v3(0.0f, 0.0f, 0.0f);
                     float o_shin = 1.0f;
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
                         sr.o = rl_v3(over, os), sr.self = rl_u(hit_prim, os), sr.q = rl_v3(hq, os), sr.dq = rl_v3(hdq, os);
-                        o_key = rl_u(pixel_key, os), o_node = rl_u(node, os);
+                        o_key = rl_u(pixel_key, os), o_node = rl_u(node, os), o_block = pass_mask;
                         if (!local_phong) o_n = rl_v3(ld3(17), os), o_eye = rl_v3(ld3(20), os), o_shin = rl_f(park[23 * 256], os);
                     } else {
                         sr.o = shfl_v3(over, owner), sr.self = shfl_u(hit_prim, owner), sr.q = shfl_v3(hq, owner), sr.dq = shfl_v3(hdq, owner);
-                        o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner);
+                        o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner), o_block = shfl_u(blockers, owner);
                         if (!local_phong) o_n = shfl_v3(ld3(17), owner), o_eye = shfl_v3(ld3(20), owner), o_shin = shfl_f(park[23 * 256], owner);
                     }
                     unsigned int my_lit = 0;
@@ -406,7 +462,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast);
+                        // an owner with an empty shaft (it is here for its Phong cells only) casts nothing
+                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && o_block != 0u, pass_mask);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);

@@ -457,6 +457,66 @@ RT_HD bool bvh_node_hit(const DPrim& n, V3 o, V3 inv_d, float t_lo, float t_hi) 
 }
 RT_HD V3 inv_dir(V3 d) { return v3(rcp_f(d.x), rcp_f(d.y), rcp_f(d.z)); }
 
+// ---------------------------------------------------------------------------------------------
+// Shafts.  The shadow rays of one shading point towards one area light (light.rs:196-208) all run
+// from the point to somewhere on the light's parallelogram, i.e. inside the union of the balls
+// B(p + s D, s r), s in [0, 1], with D = centre - p and (centre, r) a ball around the light.  A
+// record that provably stays outside that set cannot occlude any of those rays, whatever the
+// jitter: the answer "not occluded" is known without casting them.  These tests only ever say
+// "cannot block" with room to spare (>= 1e-3 relative, far above FP32 rounding of the exact
+// tests); everything else is left to the exact intersection code, so the image does not change.
+struct DBound {  // 16 B per record: world-space bounding ball (r = +inf: unbounded)
+    float c[3];
+    float r;
+};
+struct Shaft {
+    V3 p, lc, D;  // apex (the over point), light ball centre, lc - p
+    float lr, dlen, inv_d2, cosk;  // ball radius, |D|, 1/|D|^2, sqrt(1 - (lr/|D|)^2)
+    bool wide;    // apex inside or close to the light's ball: the cone bound says nothing
+};
+RT_HD void light_ball(const DLight& l, V3& c, float& r) {
+    V3 a = v3(l.uvec[0], l.uvec[1], l.uvec[2]) * (0.5f * static_cast<float>(l.usteps));
+    V3 b = v3(l.vvec[0], l.vvec[1], l.vvec[2]) * (0.5f * static_cast<float>(l.vsteps));
+    c = v3(l.pos[0], l.pos[1], l.pos[2]) + a + b;
+    r = sqrt_f(fmaxf(dot(a + b, a + b), dot(a - b, a - b))) * 1.0001f;
+}
+RT_HD Shaft make_shaft(V3 p, V3 lc, float lr) {
+    Shaft s;
+    s.p = p, s.lc = lc, s.D = lc - p, s.lr = lr;
+    float d2 = dot(s.D, s.D);
+    float k2 = lr * lr * rcp_f(d2);
+    s.wide = !(k2 < 0.9f);
+    s.inv_d2 = rcp_f(d2);
+    s.dlen = d2 * rsq_f(d2);
+    s.cosk = sqrt_f(fmaxf(1.0f - k2, 0.0f));
+    return s;
+}
+// min over s of |c - p - s D| - s lr  (a lower bound of the distance between the ball's centre and
+// the shaft) against the ball's radius.  NaN / inf radius -> true.
+RT_HD bool shaft_meets_ball(const Shaft& s, V3 c, float r) {
+    V3 e = c - s.p;
+    float t = dot(e, s.D) * s.inv_d2;
+    V3 w = madd(s.D, -t, e);
+    float perp = sqrt_f(dot(w, w));
+    float gap = perp * s.cosk - t * s.lr - 1e-5f * fmaf(fabsf(t), s.dlen, perp);
+    return s.wide | !(gap > fmaf(r, 1.001f, 1e-4f));
+}
+// Plane (plane.rs:39-51): the exact test finds t in (0, dist) only if the ray's end lies on the
+// other side of y = 0 than its origin.  oy is the origin's object-space height exactly as the
+// exact test computes it; the heights of the light's points are bounded with a margin.
+RT_HD bool shaft_meets_plane(const Shaft& s, const float* inv, float oy) {
+    float yc = fmaf(inv[4], s.lc.x, fmaf(inv[5], s.lc.y, fmaf(inv[6], s.lc.z, inv[7])));
+    float rn = sqrt_f(fmaf(inv[4], inv[4], fmaf(inv[5], inv[5], inv[6] * inv[6])));
+    float l1 = fabsf(s.lc.x) + fabsf(s.lc.y) + fabsf(s.lc.z) + fabsf(s.p.x) + fabsf(s.p.y) + fabsf(s.p.z) + s.lr;
+    float reach = fmaf(rn, s.lr, fmaf(1e-5f, fmaf(rn, l1, fabsf(yc)), 1e-6f));
+    bool above = (oy > 0.0f) & (yc - reach > 0.0f);
+    bool below = (oy < 0.0f) & (yc + reach < 0.0f);
+    return !(above | below);
+}
+// Every ray of the shaft leaves the tangent plane at the apex on the side of the normal n: a ray
+// that starts (1e-5 outside) on a CONVEX primitive with outward normal n cannot meet it again.
+RT_HD bool shaft_leaves_surface(const Shaft& s, V3 n) { return dot(s.D, n) - s.lr > 1e-3f * (s.dlen + s.lr); }
+
 // intersection.rs:71-103 without the sorted list.  The reference walks the sorted intersections up
 // to the hit, toggling each object in a container list; n1 is the material of the list's last entry
 // before the hit toggles, n2 after.  Equivalent, per primitive: it is in the list at the hit iff an

@@ -30,6 +30,7 @@ struct PackedScene {
     std::vector<DPrim> recs;      // the traversal stream
     std::vector<uint32_t> order;  // per record: the primitive's position in world.objects order (nodes: 0)
     std::vector<uint32_t> gate;   // per record: innermost enclosing Group (index into gates) or kNoGate
+    std::vector<DBound> bound;    // per record: world-space bounding ball (shaft tests)
     std::vector<DGate> gates;     // the caller's Groups
     std::vector<DExtra> extras;
     std::vector<DMaterial> mats;
@@ -37,7 +38,7 @@ struct PackedScene {
     std::vector<DLight> lights;
     uint32_t n_items = 0, n_lights = 0;  // real counts (the vectors are padded to be non-empty)
     uint32_t max_cells = 1;              // largest usteps*vsteps over the lights
-    bool has_gates = false, has_bvh = false, exotic = false;
+    bool has_gates = false, has_bvh = false, exotic = false, has_area = false;
 };
 
 constexpr uint32_t kFlatLimit = 8;  // at most this many primitives and no Groups: no hierarchy
@@ -126,6 +127,78 @@ inline HostBox prim_world_box(uint32_t type, const float* inv, const float* para
         box.mn[k] -= pad, box.mx[k] += pad;
     }
     return box;
+}
+
+// World-space bounding ball of one primitive (shaft tests, rt_math.h), from the same f32
+// transform_inverse.  Unbounded or degenerate: r = +inf ("may always block").
+inline DBound prim_world_ball(uint32_t type, const float* inv, const float* param) {
+    DBound out{{0.0f, 0.0f, 0.0f}, INFINITY};
+    double fwd[12];
+    if (type == RT_PRIM_PLANE || !invert_affine(inv, fwd)) return out;
+    double pts[8][3];
+    int n = 0;
+    if (type == RT_PRIM_TRIANGLE || type == RT_PRIM_SMOOTH_TRIANGLE) {
+        for (int k = 0; k < 3; ++k) {
+            pts[0][k] = param[k];
+            pts[1][k] = double(param[k]) + param[3 + k];
+            pts[2][k] = double(param[k]) + param[6 + k];
+        }
+        n = 3;
+    } else {
+        double y0 = -1.0, y1 = 1.0;
+        if (type == RT_PRIM_CYLINDER) y0 = param[0], y1 = param[1];
+        if (!std::isfinite(y0) || !std::isfinite(y1)) return out;
+        for (int c = 0; c < 8; ++c) pts[c][0] = (c & 1) ? 1.0 : -1.0, pts[c][1] = (c & 2) ? y1 : y0, pts[c][2] = (c & 4) ? 1.0 : -1.0;
+        n = 8;
+    }
+    double cen[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) cen[k] += pts[i][k] / n;
+    double r2 = 0.0;
+    if (type == RT_PRIM_SPHERE) {
+        // |F x| <= sqrt(lambda_max(F^T F)) for |x| = 1; Gershgorin row sums bound lambda_max
+        for (int i = 0; i < 3; ++i) {
+            double row = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                double g = 0.0;
+                for (int k = 0; k < 3; ++k) g += fwd[4 * k + i] * fwd[4 * k + j];
+                row += std::fabs(g);
+            }
+            r2 = std::max(r2, row);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double v = fwd[4 * k] * (pts[i][0] - cen[0]) + fwd[4 * k + 1] * (pts[i][1] - cen[1]) + fwd[4 * k + 2] * (pts[i][2] - cen[2]);
+                d2 += v * v;
+            }
+            r2 = std::max(r2, d2);
+        }
+    }
+    double c[3], cmax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        c[k] = fwd[4 * k] * cen[0] + fwd[4 * k + 1] * cen[1] + fwd[4 * k + 2] * cen[2] + fwd[4 * k + 3];
+        cmax = std::max(cmax, std::fabs(c[k]));
+    }
+    const double r = std::sqrt(r2) * (1.0 + 1e-5) + 1e-5 * cmax + 1e-5;
+    if (!std::isfinite(r) || !std::isfinite(cmax)) return out;
+    out.c[0] = static_cast<float>(c[0]), out.c[1] = static_cast<float>(c[1]), out.c[2] = static_cast<float>(c[2]);
+    out.r = static_cast<float>(r);
+    return out;
+}
+// Ball around a hierarchy node's box.
+inline DBound node_ball(const DPrim& node) {
+    DBound b{};
+    double r2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        b.c[k] = 0.5f * (node.inv[k] + node.inv[3 + k]);
+        const double h = 0.5 * (double(node.inv[3 + k]) - node.inv[k]);
+        r2 += h * h;
+    }
+    b.r = static_cast<float>(std::sqrt(r2) * (1.0 + 1e-5) + 1e-5);
+    if (!std::isfinite(b.r) || !std::isfinite(b.c[0]) || !std::isfinite(b.c[1]) || !std::isfinite(b.c[2])) b = DBound{{0.0f, 0.0f, 0.0f}, INFINITY};
+    return b;
 }
 
 struct BvhBuild {
@@ -325,6 +398,8 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     }
     out.n_items = static_cast<uint32_t>(out.recs.size());
     if (out.recs.empty()) out.recs.push_back(DPrim{}), out.order.push_back(0), out.gate.push_back(kNoGate);
+    for (const DPrim& r : out.recs)
+        out.bound.push_back(r.type == REC_NODE ? node_ball(r) : prim_world_ball(r.type, r.inv, out.extras[r.extra].f));
 
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         if (d->light_type[i] > RT_LIGHT_AREA) {
@@ -337,6 +412,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         std::memcpy(l.vvec, d->light_vvec + 3 * i, sizeof(l.vvec));
         std::memcpy(l.color, d->light_color + 3 * i, sizeof(l.color));
         l.type = d->light_type[i];
+        out.has_area |= l.type == RT_LIGHT_AREA;
         l.usteps = l.type == RT_LIGHT_AREA ? d->light_usteps[i] : 1u;
         l.vsteps = l.type == RT_LIGHT_AREA ? d->light_vsteps[i] : 1u;
         if (l.usteps == 0 || l.vsteps == 0) return bad("area light with zero cells");

@@ -6,6 +6,7 @@
 // driven by a plain scalar loop.  Wave-level orchestration (ballots, cooperative area-light
 // sampling, the threaded traversal's uniform jumps) is NOT simulated — that is covered by the
 // `-m gpu` tests.  Never linked into the product library; the product has no CPU path.
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,69 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
     cs.finish(hit_ior, n1, n2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Audit of the kernel's shaft tests (rt_math.h "Shafts", rt_kernel.h area-light pass).  The kernel
+// skips the shadow rays of a (shading point, area light) pair against every record its shaft test
+// rules out.  Here the same tests are evaluated, then EVERY primitive is tested exactly against
+// rays to the jittered point and to the four corners of every light cell: a primitive that
+// occludes one of them although it was ruled out is a violation (there must be none).
+std::atomic<bool> g_audit{false};
+std::atomic<uint64_t> g_audit_pairs{0}, g_audit_ruled_out{0}, g_audit_open{0}, g_audit_violations{0};
+
+void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key, uint32_t node, V3 over, const HitInfo& h,
+                 uint32_t self) {
+    const uint32_t n = s.ps.n_items;
+    std::vector<uint8_t> may(n, 0);
+    V3 lcen;
+    float lrad;
+    light_ball(l, lcen, lrad);
+    const Shaft sh = make_shaft(over, lcen, lrad);
+    const bool self_clear = !h.inside && shaft_leaves_surface(sh, h.n);
+    uint32_t prims = 0, ruled_out = 0;
+    for (uint32_t i = 0; i < n;) {  // the walk of rt_kernel.h, one "lane"
+        const DPrim& r = s.ps.recs[i];
+        const DBound& b = s.ps.bound[i];
+        if (r.type == REC_NODE) {
+            i = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r) ? i + 1 : r.material;
+            continue;
+        }
+        bool mb;
+        if (i == self) mb = r.type >= PRIM_CYLINDER || !self_clear;
+        else if (r.type == PRIM_PLANE)
+            mb = shaft_meets_plane(sh, r.inv, fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
+        else mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+        may[i] = mb;
+        ++i;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (s.ps.recs[i].type != REC_NODE) ++prims, ruled_out += may[i] ? 0u : 1u;
+    g_audit_pairs += 1, g_audit_ruled_out += ruled_out, g_audit_open += (ruled_out == prims) ? 1u : 0u;
+    if (ruled_out == 0) return;
+    const uint32_t cells = l.usteps * l.vsteps;
+    for (uint32_t cell = 0; cell < cells; ++cell) {
+        const uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
+        float ju = 0.5f, jv = 0.5f;
+        if (s.jitter_mode == RT_JITTER_COUNTER) counter_jitter(pixel_key, node, li, cell, ju, jv);
+        const float us[5] = {ju, 0.0f, 1.0f, 0.0f, 1.0f}, vs[5] = {jv, 0.0f, 0.0f, 1.0f, 1.0f};
+        for (int k = 0; k < 5; ++k) {
+            const V3 tl = point_on_light(l, cu, cv, us[k], vs[k]) - over;
+            const float dist2 = dot(tl, tl);
+            if (!(dist2 > kEps * kEps)) continue;
+            const float inv_dist = rsq_f(dist2), dist = dist2 * inv_dist;
+            Ray sr;
+            sr.o = over, sr.d = tl * inv_dist, sr.self = self, sr.q = h.q, sr.dq = h.dq;
+            for (uint32_t i = 0; i < n; ++i) {
+                const DPrim& p = s.ps.recs[i];
+                if (p.type == REC_NODE || may[i]) continue;
+                bool hit = false;
+                if (i == self) intersect_prim(p, s.ps.extras.data(), sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+                else hit = occludes_prim(p, s.ps.extras.data(), sr.o, sr.d, dist);
+                if (hit && gated_in(s, i, sr)) g_audit_violations += 1;
+            }
+        }
+    }
+}
+
 struct PathNode {
     Ray ray;
     V3 w;
@@ -128,6 +192,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
                 V3 lc = v3(l.color[0], l.color[1], l.color[2]);
                 V3 ec = pc * lc;
                 uint32_t cells = l.usteps * l.vsteps;
+                if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, c.prim);
                 uint32_t lit = 0;
                 float sum_d = 0.0f, sum_s = 0.0f;
                 for (uint32_t cell = 0; cell < cells; ++cell) {
@@ -247,4 +312,17 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
         });
     for (auto& th : pool) th.join();
     return RT_OK;
+}
+
+// Renders like hostsim_render with the shaft audit switched on.  out[0] = (point, area light) pairs
+// audited, out[1] = primitives ruled out in total, out[2] = pairs with every primitive ruled out,
+// out[3] = violations.
+extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
+                                   float* rgb_out, uint64_t* out, char* err_out, int err_cap) {
+    g_audit_pairs = 0, g_audit_ruled_out = 0, g_audit_open = 0, g_audit_violations = 0;
+    g_audit = true;
+    const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
+    g_audit = false;
+    out[0] = g_audit_pairs, out[1] = g_audit_ruled_out, out[2] = g_audit_open, out[3] = g_audit_violations;
+    return rc;
 }
