@@ -40,6 +40,9 @@
 #ifndef RT_EXP
 #define RT_EXP 0  // timing experiments only (scripts/exp_variants.sh): knock out one phase of the shading pass
 #endif
+#ifndef RT_MIN_BLOCKS
+#define RT_MIN_BLOCKS 4  // 256-thread blocks per CU = waves per SIMD (occupancy sweeps override it)
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // request record i+1 while record i is processed (costs 16 SGPR copies per record)
 #endif
@@ -182,7 +185,7 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
 // hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
-__global__ __launch_bounds__(256, 4) void render_kernel(const KParams P) {
+__global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave >= P.n_tiles) return;
