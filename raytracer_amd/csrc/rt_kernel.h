@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
 
     StackEntry stack[kStackCap];
     int sp = 0;
-    __shared__ float s_park[24 * 256];
+    // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
+    // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
+    __shared__ float s_park[(AREA ? 34 : 24) * 256];
     float* const park = s_park + threadIdx.x;
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
@@ -310,6 +312,17 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         park[8 * 256] = pc.x, park[9 * 256] = pc.y, park[10 * 256] = pc.z;
         park[11 * 256] = m_ambient, park[12 * 256] = m_diffuse, park[13 * 256] = m_specular;
         park[14 * 256] = 0.0f, park[15 * 256] = 0.0f, park[16 * 256] = 0.0f;  // surface colour so far
+        if (AREA) {
+            park[24 * 256] = over.x, park[25 * 256] = over.y, park[26 * 256] = over.z;
+            park[27 * 256] = hq.x, park[28 * 256] = hq.y, park[29 * 256] = hq.z;
+            park[30 * 256] = hdq.x, park[31 * 256] = hdq.y, park[32 * 256] = hdq.z;
+            park[33 * 256] = __uint_as_float(hit_prim);
+        }
+        // the hit's data as the light loops see it
+        auto h_over = [&] { return AREA ? ld3(24) : over; };
+        auto h_q = [&] { return AREA ? ld3(27) : hq; };
+        auto h_dq = [&] { return AREA ? ld3(30) : hdq; };
+        auto h_prim = [&] { return AREA ? __float_as_uint(park[33 * 256]) : hit_prim; };
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             const DLight l = sc.lights[li];
             const V3 lc = v3(l.color[0], l.color[1], l.color[2]);
@@ -317,17 +330,18 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
             if (!AREA || l.type == RT_LIGHT_POINT) {
                 // light.rs:182-188 + material.rs:138-159 with a single cell
                 const V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
-                const V3 tl = lp - over;
+                const V3 p_over = h_over();
+                const V3 tl = lp - p_over;
                 const float dist2 = dot(tl, tl);
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
-                if (shades) phong_cell(lp, over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
+                if (shades) phong_cell(lp, p_over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
                 // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
                 // ray cannot change the pixel and is answered without tracing
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
-                sr.o = over, sr.d = tl * inv_dist, sr.self = hit_prim, sr.q = hq, sr.dq = hdq;
+                sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
                 const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters, ~0u);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
@@ -355,11 +369,12 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     V3 lcen;
                     float lrad;
                     light_ball(l, lcen, lrad);
-                    const Shaft sh = make_shaft(over, lcen, lrad);
+                    const V3 p_over = h_over();
+                    const Shaft sh = make_shaft(p_over, lcen, lrad);
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
                     blockers = 0u;
                     traverse<TREE>(
-                        sc, hit_prim, shades, ~0u,
+                        sc, h_prim(), shades, ~0u,
                         [&](uint32_t i, const DPrim&) {
                             const DBound b = sc.bound[i];
                             return shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                             if (decltype(self)::value) {
                                 mb = p.type >= PRIM_CYLINDER || !self_clear;  // convex shapes only
                             } else if (p.type == PRIM_PLANE) {
-                                mb = shaft_meets_plane(sh, p.inv, fmaf(p.inv[4], over.x, fmaf(p.inv[5], over.y, fmaf(p.inv[6], over.z, p.inv[7]))));
+                                mb = shaft_meets_plane(sh, p.inv, fmaf(p.inv[4], p_over.x, fmaf(p.inv[5], p_over.y, fmaf(p.inv[6], p_over.z, p.inv[7]))));
                             } else {
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 // (chunk 0) and is broadcast with v_readlane; summed in cell order.
                 const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
                 if (local_phong && !(RT_EXP & 2)) {
-                    const V3 p_n = ld3(17), p_eye = ld3(20);
+                    const V3 p_n = ld3(17), p_eye = ld3(20), p_over = h_over();
                     const float p_shin = park[23 * 256];
                     for (uint32_t c = 0; c < cells; ++c) {
                         V3 centre;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                             centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
                         }
                         float ldn = 0.0f, spec = 0.0f;
-                        if (shades) phong_cell(centre, over, p_n, p_eye, p_shin, ldn, spec);
+                        if (shades) phong_cell(centre, p_over, p_n, p_eye, p_shin, ldn, spec);
                         sum_d += ldn, sum_s += spec;
                     }
                     if (STATS && shades) c_cells += cells;
@@ -429,15 +444,17 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     uint32_t o_key, o_node, o_block;
                     V3 o_n = v3(0.0f, 0.0f, 0.0f), o_eye = v3(0.0f, 0.0f, 0.0f);
                     float o_shin = 1.0f;
+                    {  // the owner's hit data: its LDS slots, read by every lane of its group (a broadcast)
+                        const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
+                        auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
+                        sr.o = od3(24), sr.q = od3(27), sr.dq = od3(30), sr.self = __float_as_uint(op[33 * 256]);
+                        if (!local_phong) o_n = od3(17), o_eye = od3(20), o_shin = op[23 * 256];
+                    }
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
-                        sr.o = rl_v3(over, os), sr.self = rl_u(hit_prim, os), sr.q = rl_v3(hq, os), sr.dq = rl_v3(hdq, os);
                         o_key = rl_u(pixel_key, os), o_node = rl_u(node, os), o_block = pass_mask;
-                        if (!local_phong) o_n = rl_v3(ld3(17), os), o_eye = rl_v3(ld3(20), os), o_shin = rl_f(park[23 * 256], os);
                     } else {
-                        sr.o = shfl_v3(over, owner), sr.self = shfl_u(hit_prim, owner), sr.q = shfl_v3(hq, owner), sr.dq = shfl_v3(hdq, owner);
                         o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner), o_block = shfl_u(blockers, owner);
-                        if (!local_phong) o_n = shfl_v3(ld3(17), owner), o_eye = shfl_v3(ld3(20), owner), o_shin = shfl_f(park[23 * 256], owner);
                     }
                     unsigned int my_lit = 0;
                     float my_d = 0.0f, my_s = 0.0f;
@@ -502,6 +519,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         acc = v3(park[3 * 256], park[4 * 256], park[5 * 256]);
         n1 = park[6 * 256], n2 = park[7 * 256];
         nrm = ld3(17);
+        if (AREA) over = ld3(24), hq = ld3(27), hdq = ld3(30), hit_prim = __float_as_uint(park[33 * 256]);
         const V3 eye = ld3(20);
         if (has_hit) acc = acc + w * v3(park[14 * 256], park[15 * 256], park[16 * 256]);
 
