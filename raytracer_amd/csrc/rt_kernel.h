@@ -267,12 +267,18 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         }
 
         // ---------------------------------------------------------------- containers (intersection.rs:71-103)
-        if (wave_any(need_n)) {
+        if (!(RT_EXP & 64) && wave_any(need_n)) {
             ContainerScan cs;
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
+            const V3 hp = madd(cur.d, hit_t, cur.o);
+            const float hm = container_margin(hit_t, hp);
             traverse<TREE>(
                 sc, cur.self, need_n, ~0u,
-                [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, INFINITY); },  // every crossing counts
+                [&](uint32_t, const DPrim& nd) {
+                    // crossings behind the origin count too (sorted list), those beyond the hit never
+                    if (EXOTIC) return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, hit_t + tie_window(hit_t));
+                    return node_holds_point(nd, hp, hm);  // rt_math.h: spheres and cubes only
+                },
                 [&](uint32_t prim, const DPrim& p, auto self) {
                     Hits hh;
                     hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
-                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters, ~0u);
+                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), ~0u);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && has_hit) c_cells++;

@@ -456,6 +456,19 @@ RT_HD bool bvh_node_hit(const DPrim& n, V3 o, V3 inv_d, float t_lo, float t_hi) 
     return tn <= tf;
 }
 RT_HD V3 inv_dir(V3 d) { return v3(rcp_f(d.x), rcp_f(d.y), rcp_f(d.z)); }
+// Node test of the container pass (intersection.rs:71-103).  Only a primitive with an ODD number of
+// crossings before the hit is in the container list at the hit; a sphere or a cube is convex and
+// crossed twice or never, so that means the hit point lies between its two crossings — inside it, or
+// within the tie window of its surface — and therefore inside every hierarchy box around it, padded
+// by that window.  (Open cylinders and triangles can be crossed once; scenes holding them keep the
+// ray-interval test.)  m = the padding, in world units.
+RT_HD bool node_holds_point(const DPrim& n, V3 p, float m) {
+    return (p.x >= n.inv[0] - m) & (p.x <= n.inv[3] + m) & (p.y >= n.inv[1] - m) & (p.y <= n.inv[4] + m) & (p.z >= n.inv[2] - m) &
+           (p.z <= n.inv[5] + m);
+}
+RT_HD float container_margin(float t_hit, V3 p) {
+    return 8.0f * tie_window(t_hit) + 1e-4f + 1e-5f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Shafts.  The shadow rays of one shading point towards one area light (light.rs:196-208) all run

@@ -86,14 +86,23 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
 // crossing before the hit has the largest t.
 void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2) {
     ContainerScan cs;
-    traverse(s, ray, -INFINITY, [&] { return INFINITY; }, [&](uint32_t prim, const DPrim& p) {
+    const V3 hp = madd(ray.d, t_hit, ray.o);
+    const float hm = container_margin(t_hit, hp);
+    const V3 inv_d = inv_dir(ray.d);
+    for (uint32_t i = 0; i < s.ps.n_items;) {  // the kernel's container walk: its own node test
+        const DPrim& p = s.ps.recs[i];
+        if (p.type == REC_NODE) {
+            const bool in = s.ps.exotic ? bvh_node_hit(p, ray.o, inv_d, -INFINITY, t_hit + tie_window(t_hit)) : node_holds_point(p, hp, hm);
+            i = in ? i + 1 : p.material;
+            continue;
+        }
+        const uint32_t prim = i++;
         Hits h;
         h.t[0] = h.t[1] = h.t[2] = h.t[3] = RT_NOHIT;
         bool any = false;
         intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot] = t, any = true; });
         if (any && gated_in(s, prim, ray)) cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit);
-        return true;
-    });
+    }
     cs.finish(hit_ior, n1, n2);
 }
 
