@@ -147,6 +147,30 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
     }
 }
 
+#if RT_EXP & 256
+// experiment: every lane walks the stream on its own (per-lane record loads, divergent control)
+template <class Enter, class Visit>
+__device__ __forceinline__ void traverse_lane(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
+    const uint32_t n = sc.n_items;
+    uint32_t i = 0;
+    bool go = live && n != 0u;
+    while (wave_any(go)) {
+        if (go) {
+            const DPrim rec = sc.recs[i];
+            uint32_t to = i + 1u;
+            if (rec.type == REC_NODE) {
+                if (!enter_node(i, rec)) to = rec.material;
+            } else {
+                const bool keep = (i == self_prim) ? visit(i, rec, std::true_type{}) : visit(i, rec, std::false_type{});
+                if (!keep) to = n;
+            }
+            i = to;
+            go = i < n;
+        }
+    }
+}
+#endif
+
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 template <bool EXOTIC, bool TREE>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, uint32_t mask) {
@@ -228,10 +252,8 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if ((TREE && sc.has_bvh)) inv_d = inv_dir(cur.d);
-        traverse<TREE>(
-            sc, cur.self, active, ~0u,
-            [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); },
-            [&](uint32_t prim, const DPrim& p, auto self) {
+        auto trace_enter = [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); };
+        auto trace_visit = [&](uint32_t prim, const DPrim& p, auto self) {
                 intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
                     // intersection.rs:105-120: smallest t > 0, world.objects order among approximately equal ones
                     bool better = closer_hit(t, hit_t);
@@ -240,7 +262,12 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     if (better) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;
                 });
                 return true;
-            });
+            };
+#if RT_EXP & 256
+        if (TREE && wave_any(active && node != 0u)) traverse_lane(sc, cur.self, active, trace_enter, trace_visit);
+        else
+#endif
+            traverse<TREE>(sc, cur.self, active, ~0u, trace_enter, trace_visit);
         const bool has_hit = active && hit_prim != kNoPrim;
         const uint32_t depth = P.max_depth - level_of(node);  // remaining recursion depth of this node
 
