@@ -96,23 +96,42 @@ __device__ __forceinline__ V3 rl_v3(V3 v, int src) { return V3{rl_f(v.x, src), r
 // so the two variants of the intersection code almost never run in the same iteration.  With 4
 // waves per SIMD the load latency is covered by the other waves; requesting record i+1 ahead
 // (RT_PREFETCH) measured slower because of the 16 SGPR copies per record.
-// Flat streams (TREE = false) take a wave-uniform `mask`: record i is visited only if bit min(i, 31)
-// is set (the shaft tests of the area-light pass clear the bits of records that cannot block).
+//
+// traverse_masked visits exactly the PRIMITIVE records a wave-uniform bit mask names (bit min(i, 63)
+// stands for record i), nodes are never looked at: flat streams are walked this way (all ones), and
+// so are the shadow passes of an area light, whose shaft tests (rt_math.h) have cleared the bits of
+// every record that cannot block.
+template <bool TREE, class Visit>
+__device__ __forceinline__ void traverse_masked(const KScene& sc, uint32_t self_prim, bool live, unsigned long long mask, Visit&& visit) {
+    const uint32_t n = sc.n_items;
+    auto one = [&](uint32_t i) {
+        const DPrim rec = sc.recs[i];
+        if (TREE && rec.type == REC_NODE) return;  // all-ones masks only
+        const bool on_self = live && i == self_prim;
+        if (wave_any(on_self)) {
+            if (on_self) live = visit(i, rec, std::true_type{});
+        }
+        if (live && !on_self) live = visit(i, rec, std::false_type{});
+    };
+    unsigned long long m = mask & 0x7FFFFFFFFFFFFFFFull;
+    while (m) {
+        const uint32_t i = static_cast<uint32_t>(__builtin_ctzll(m));
+        m &= m - 1ull;
+        if (i >= n || !wave_any(live)) return;
+        one(i);
+    }
+    if (mask >> 63)
+        for (uint32_t i = 63; i < n; ++i) {
+            if (!wave_any(live)) return;
+            one(i);
+        }
+}
 template <bool TREE, class Enter, class Visit>
-__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, uint32_t mask, Enter&& enter_node, Visit&& visit) {
+__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
     if (!TREE) {
-        for (uint32_t i = 0; i < n; ++i) {
-            if (!((mask >> (i < 31u ? i : 31u)) & 1u)) continue;
-            if (!wave_any(live)) break;
-            const DPrim rec = sc.recs[i];
-            const bool on_self = live && i == self_prim;
-            if (wave_any(on_self)) {
-                if (on_self) live = visit(i, rec, std::true_type{});
-            }
-            if (live && !on_self) live = visit(i, rec, std::false_type{});
-        }
+        traverse_masked<false>(sc, self_prim, live, ~0ull, visit);
         return;
     }
     uint32_t i = 0;
@@ -173,13 +192,9 @@ __device__ __forceinline__ void traverse_lane(const KScene& sc, uint32_t self_pr
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 template <bool EXOTIC, bool TREE>
-__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, uint32_t mask) {
+__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask) {
     bool occ = false;
-    V3 inv_d = v3(0.0f, 0.0f, 0.0f);
-    if ((TREE && sc.has_bvh)) inv_d = inv_dir(ray.d);
-    traverse<TREE>(
-        sc, ray.self, live, mask, [&](uint32_t, const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); },
-        [&](uint32_t prim, const DPrim& p, auto self) {
+    auto visit = [&](uint32_t prim, const DPrim& p, auto self) {
             bool hit = false;
             if (decltype(self)::value)
                 intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
@@ -192,7 +207,14 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
             if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
             occ = hit;
             return !occ;
-        });
+        };
+    if (!TREE || masked) {
+        traverse_masked<TREE>(sc, ray.self, live, mask, visit);
+    } else {
+        V3 inv_d = v3(0.0f, 0.0f, 0.0f);
+        if (sc.has_bvh) inv_d = inv_dir(ray.d);
+        traverse<TREE>(sc, ray.self, live, [&](uint32_t, const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); }, visit);
+    }
     return occ;
 }
 
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         if (TREE && wave_any(active && node != 0u)) traverse_lane(sc, cur.self, active, trace_enter, trace_visit);
         else
 #endif
-            traverse<TREE>(sc, cur.self, active, ~0u, trace_enter, trace_visit);
+            traverse<TREE>(sc, cur.self, active, trace_enter, trace_visit);
         const bool has_hit = active && hit_prim != kNoPrim;
         const uint32_t depth = P.max_depth - level_of(node);  // remaining recursion depth of this node
 
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
             traverse<TREE>(
-                sc, cur.self, need_n, ~0u,
+                sc, cur.self, need_n,
                 [&](uint32_t, const DPrim& nd) {
                     // crossings behind the origin count too (sorted list), those beyond the hit never
                     if (EXOTIC) return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, hit_t + tie_window(hit_t));
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
-                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), ~0u);
+                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && has_hit) c_cells++;
@@ -395,9 +417,11 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 if (STATS && has_hit && !shades) c_shadow += cells, c_cells += cells;  // the reference casts them all the same
 
                 // Shaft tests (rt_math.h): which records could occlude ANY ray from this lane's point
-                // to this light, whatever the jitter.  Flat stream: one bit per record; hierarchy:
-                // nonzero = something might.  A point with none is fully lit without casting.
-                uint32_t blockers = shades ? ~0u : 0u;
+                // to this light, whatever the jitter.  Streams of up to 64 records: one bit per
+                // primitive record; longer ones: nonzero = something might.  A point with none is
+                // fully lit without casting.
+                const bool by_mask = !TREE || sc.n_items <= 64u;
+                unsigned long long blockers = shades ? ~0ull : 0ull;
                 if (!(RT_EXP & 32) && wave_any(shades)) {
                     V3 lcen;
                     float lrad;
@@ -405,9 +429,9 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const V3 p_over = h_over();
                     const Shaft sh = make_shaft(p_over, lcen, lrad);
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
-                    blockers = 0u;
+                    blockers = 0ull;
                     traverse<TREE>(
-                        sc, h_prim(), shades, ~0u,
+                        sc, h_prim(), shades,
                         [&](uint32_t i, const DPrim&) {
                             const DBound b = sc.bound[i];
                             return shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
@@ -422,11 +446,11 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
                             }
-                            if (mb) blockers |= TREE ? 1u : (1u << (prim < 31u ? prim : 31u));
-                            return !(TREE && mb);
+                            if (mb) blockers |= 1ull << (prim < 63u ? prim : 63u);
+                            return by_mask || !mb;  // without a mask the first possible blocker settles it
                         });
                 }
-                const bool open = shades && blockers == 0u;
+                const bool open = shades && blockers == 0ull;
                 if (open) lit = static_cast<float>(cells);
 
                 // Phong sums over the cell centres.  Lane-local when at least half of the lanes'
@@ -462,19 +486,22 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 while (need) {
                     // the shading points ("owners") of this pass: one per slot of g lanes
                     int owner = 0;
-                    uint32_t my_slot = 0, taken = 0, pass_mask = 0;
+                    uint32_t my_slot = 0, taken = 0;
+                    unsigned long long pass_mask = 0;
                     bool owner_now = false;
                     for (uint32_t k = 0; k < slots && need; ++k) {
                         const int o = __ffsll(static_cast<long long>(need)) - 1;
                         need &= need - 1ull;
-                        pass_mask |= rl_u(blockers, o);
+                        pass_mask |= static_cast<unsigned long long>(rl_u(static_cast<uint32_t>(blockers), o)) |
+                                     (static_cast<unsigned long long>(rl_u(static_cast<uint32_t>(blockers >> 32), o)) << 32);
                         if (slot == k) owner = o;
                         if (static_cast<int>(lane) == o) my_slot = k, owner_now = true;
                         taken = k + 1;
                     }
                     const bool lane_on = slot < taken;
                     Ray sr;
-                    uint32_t o_key, o_node, o_block;
+                    uint32_t o_key, o_node;
+                    bool o_block;
                     V3 o_n = v3(0.0f, 0.0f, 0.0f), o_eye = v3(0.0f, 0.0f, 0.0f);
                     float o_shin = 1.0f;
                     {  // the owner's hit data: its LDS slots, read by every lane of its group (a broadcast)
@@ -485,9 +512,9 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     }
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
-                        o_key = rl_u(pixel_key, os), o_node = rl_u(node, os), o_block = pass_mask;
+                        o_key = rl_u(pixel_key, os), o_node = rl_u(node, os), o_block = pass_mask != 0ull;
                     } else {
-                        o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner), o_block = shfl_u(blockers, owner);
+                        o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner), o_block = shfl_u(blockers != 0ull ? 1u : 0u, owner) != 0u;
                     }
                     unsigned int my_lit = 0;
                     float my_d = 0.0f, my_s = 0.0f;
@@ -516,7 +543,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                         const bool occ = cast && dist > 1e30f;
 #else
                         // an owner with an empty shaft (it is here for its Phong cells only) casts nothing
-                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && o_block != 0u, pass_mask);
+                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && o_block, by_mask, pass_mask);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
