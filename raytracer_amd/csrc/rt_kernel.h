@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
-                if (shades) phong_cell(lp, p_over, ld3(17), ld3(20), park[23 * 256], sum_d, sum_s);
+                if (shades) phong_cell(phong_point(p_over, ld3(17), ld3(20), park[23 * 256]), lp, sum_d, sum_s);
                 // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
                 // ray cannot change the pixel and is answered without tracing
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
@@ -458,8 +458,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 // (chunk 0) and is broadcast with v_readlane; summed in cell order.
                 const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
                 if (local_phong && !(RT_EXP & 2)) {
-                    const V3 p_n = ld3(17), p_eye = ld3(20), p_over = h_over();
-                    const float p_shin = park[23 * 256];
+                    const PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
                     for (uint32_t c = 0; c < cells; ++c) {
                         V3 centre;
                         if (c < 64u) {
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                             centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
                         }
                         float ldn = 0.0f, spec = 0.0f;
-                        if (shades) phong_cell(centre, p_over, p_n, p_eye, p_shin, ldn, spec);
+                        if (shades) phong_cell(pp, centre, ldn, spec);
                         sum_d += ldn, sum_s += spec;
                     }
                     if (STATS && shades) c_cells += cells;
@@ -550,7 +549,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
                         if (!local_phong) {  // few lanes have a hit: their Phong cells ride along, one per lane
                             float ldn = 0.0f, spec = 0.0f;
-                            if (con) phong_cell(centre, sr.o, o_n, o_eye, o_shin, ldn, spec);
+                            if (con) phong_cell(phong_point(sr.o, o_n, o_eye, o_shin), centre, ldn, spec);
                             for (uint32_t s = 1; s < g; s <<= 1) {  // butterfly inside the slot's lane group
                                 ldn += __shfl_xor(ldn, static_cast<int>(s), 64);
                                 spec += __shfl_xor(spec, static_cast<int>(s), 64);

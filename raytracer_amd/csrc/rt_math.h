@@ -683,32 +683,48 @@ RT_HD V3 pattern_color(const DPattern& pat, V3 obj_point) {
 
 // material.rs:138-159 for ONE light cell: returns (light . normal) and the specular factor, both
 // already gated (0 when the reference skips them).
-RT_HD void phong_cell(V3 cell, V3 point, V3 n, V3 eye, float shininess, float& ldn_out, float& spec_out) {
-    V3 lv = cell - point;
+// One shading point's side of material.rs:138-159; the part that does not depend on the light cell.
+struct PhongPoint {
+    V3 p, n, eye;
+    float shininess;
+    float n_eye;  // n . eye
+    float gate;   // (reflect . eye) below this: the specular factor is < 2^-36 and dropped
+};
+RT_HD PhongPoint phong_point(V3 p, V3 n, V3 eye, float shininess) {
+    PhongPoint q;
+    q.p = p, q.n = n, q.eye = eye, q.shininess = shininess;
+    q.n_eye = dot(n, eye);
+    q.gate = shininess > 0.0f ? exp2f(-36.0f / shininess) : 0.0f;
+    return q;
+}
+RT_HD void phong_cell(const PhongPoint& q, V3 cell, float& ldn_out, float& spec_out) {
+    V3 lv = cell - q.p;
     float len2 = dot(lv, lv);
-    V3 lightv = (len2 <= kEps * kEps) ? v3(0.0f, 0.0f, 0.0f) : lv * rsq_f(len2);  // normalize().unwrap_or(0)
-    float ldn = dot(lightv, n);
+    float inv = (len2 <= kEps * kEps) ? 0.0f : rsq_f(len2);  // normalize().unwrap_or(0)
+    float ldn = dot(lv, q.n) * inv;
     ldn_out = 0.0f;
     spec_out = 0.0f;
     if (ldn >= -kEps) {  // float::ge(light_dot_normal, 0.0)
         ldn_out = ldn;
-        V3 ml = neg(lightv);
-        V3 rv = ml - n * 2.0f * dot(ml, n);  // (-lightv).reflect(normalv)
-        float rde = dot(rv, eye);
+        // (-lightv).reflect(normalv) . eye = 2 (lightv.n)(n.eye) - lightv.eye: five instructions a
+        // cell; the reflected vector itself is only formed inside a highlight.
         // factor = (reflect . eye)^shininess (material.rs:150-153).  Outside the highlight the factor
         // is below 2^-36 and is dropped (1e-11 of a colour unit) — most cells of most shading points,
         // so the wave usually skips the power altogether.
-        if (rde > 0.0f && shininess * fast_log2(rde) > -36.0f) {
+        float rde_fast = fmaf(2.0f * ldn, q.n_eye, -(dot(lv, q.eye) * inv));
+        if (rde_fast > q.gate) {
             // x^200 turns the 1e-7 absolute rounding error of an FP32 dot product of two unit
             // vectors into 2e-5 RELATIVE error on highlights whose value exceeds 1, so cos(theta) is
             // taken from the cross product instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full
             // relative accuracy in (1 - cos), and the power is exp(shininess/2 * log1p(-sin^2)).
-            V3 cx = cross_exact(rv, eye);
-            float sin2 = fminf(div_f(dot(cx, cx), dot(rv, rv) * dot(eye, eye)), 1.0f);
+            V3 ml = neg(lv * inv);
+            V3 rv = ml - q.n * 2.0f * dot(ml, q.n);
+            V3 cx = cross_exact(rv, q.eye);
+            float sin2 = fminf(div_f(dot(cx, cx), dot(rv, rv) * dot(q.eye, q.eye)), 1.0f);
             if (sin2 < 0.25f)
-                spec_out = expf(0.5f * shininess * log1pf(-sin2));
+                spec_out = expf(0.5f * q.shininess * log1pf(-sin2));
             else
-                spec_out = powf(rde, shininess);
+                spec_out = powf(dot(rv, q.eye), q.shininess);
         }
     }
 }

@@ -221,7 +221,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
                     if (!shadowed) ++lit;
                     V3 centre = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, 0.5f, 0.5f) : lp;
                     float ldn, spec;
-                    phong_cell(centre, over, h.n, h.eye, m.shininess, ldn, spec);
+                    phong_cell(phong_point(over, h.n, h.eye, m.shininess), centre, ldn, spec);
                     sum_d += ldn, sum_s += spec;
                 }
                 float intensity = static_cast<float>(lit) * l.inv_samples;

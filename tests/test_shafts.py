@@ -137,3 +137,41 @@ def test_no_occluder_is_ruled_out_in_random_scenes(n_objects):
             tot[k] += r[k]
     assert tot["pairs"] > 1000 and tot["violations"] == 0, tot
     assert tot["ruled_out"] > 0, tot
+
+
+def many_planes_scene(rng, keep, n_planes=70):
+    """Flat stream longer than the 64-bit record mask: a floor, n_planes - 1 more planes underneath it
+    (never visible, but in the stream), and two spheres (<= 2 bounded primitives: no hierarchy)."""
+    d = random_scene(rng, 2, keep)
+    n0 = d.n_prims
+    types = np.ctypeslib.as_array(C.cast(d.prim_type, C.POINTER(C.c_uint8)), (n0,)).copy()
+    invs = np.ctypeslib.as_array(C.cast(d.prim_inv, C.POINTER(C.c_float)), (n0, 12)).copy()
+    mats = np.ctypeslib.as_array(C.cast(d.prim_material, C.POINTER(C.c_uint32)), (n0,)).copy()
+    keepi = [i for i in range(n0) if types[i] != 1 or i == 0]  # drop a possible wall, keep floor + spheres
+    types, invs, mats = types[keepi], invs[keepi], mats[keepi]
+    extra = []
+    for k in range(1, n_planes):
+        m = np.eye(4)
+        m[1, 3] = float(k)  # inverse of translation(0, -k, 0)
+        extra.append(m[:3, :].reshape(12))
+    order = [0] + list(range(len(types), len(types) + len(extra))) + list(range(1, len(types)))  # spheres LAST (records >= 63)
+    types = np.concatenate([types, np.ones(len(extra), dtype=np.uint8)])[order]
+    invs = np.concatenate([invs, np.array(extra, dtype=np.float32)])[order]
+    mats = np.concatenate([mats, np.zeros(len(extra), dtype=np.uint32)])[order]
+    n = len(types)
+    params = np.zeros((n, 24), dtype=np.float32)
+    ref, nxt = np.arange(n, dtype=np.uint32), np.arange(1, n + 1, dtype=np.uint32)
+    types, invs, mats = np.ascontiguousarray(types), np.ascontiguousarray(invs), np.ascontiguousarray(mats)
+    keep += [types, invs, mats, params, ref, nxt]
+    d.n_prims, d.prim_type, d.prim_inv = n, types.ctypes.data, invs.ctypes.data
+    d.prim_material, d.prim_param = mats.ctypes.data, params.ctypes.data
+    d.n_items, d.item_ref, d.item_next = n, ref.ctypes.data, nxt.ctypes.data
+    return d
+
+
+def test_no_occluder_is_ruled_out_on_a_flat_stream_longer_than_the_mask():
+    cam = ExampleScene("striped_sphere_multiple_lights", 40, 24)
+    keep = []
+    d = many_planes_scene(np.random.default_rng(7), keep)
+    r = audit(C.pointer(d), cam.camera_desc, seed=1)
+    assert r["pairs"] > 100 and r["violations"] == 0 and r["ruled_out"] > 0, r
