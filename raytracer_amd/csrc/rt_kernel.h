@@ -104,6 +104,28 @@ __device__ __forceinline__ V3 rl_v3(V3 v, int src) { return V3{rl_f(v.x, src), r
 template <bool TREE, class Visit>
 __device__ __forceinline__ void traverse_masked(const KScene& sc, uint32_t self_prim, bool live, unsigned long long mask, Visit&& visit) {
     const uint32_t n = sc.n_items;
+    if (!TREE) {  // flat streams are short: a plain loop, 32 mask bits (bit 31 = every record from 31 on)
+        const uint32_t m32 = static_cast<uint32_t>(mask);
+        uint32_t m = m32 & (n >= 31u ? 0x7FFFFFFFu : ((1u << n) - 1u));
+        uint32_t i = 0;
+        for (;;) {
+            if (m) {
+                i = static_cast<uint32_t>(__builtin_ctz(m));
+                m &= m - 1u;
+            } else {  // records from 31 on share bit 31
+                i = i < 31u ? 31u : i + 1u;
+                if (!(m32 >> 31) || i >= n) break;
+            }
+            if (!wave_any(live)) break;
+            const DPrim rec = sc.recs[i];
+            const bool on_self = live && i == self_prim;
+            if (wave_any(on_self)) {
+                if (on_self) live = visit(i, rec, std::true_type{});
+            }
+            if (live && !on_self) live = visit(i, rec, std::false_type{});
+        }
+        return;
+    }
     auto one = [&](uint32_t i) {
         const DPrim rec = sc.recs[i];
         if (TREE && rec.type == REC_NODE) return;  // all-ones masks only
@@ -230,6 +252,16 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // (profiles/r01_occupancy_sweep.txt); 5 and more spill too much.
 // EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
 // hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
+// The pixel of a lane: column x, row yl of this call's packed output, global row gy; false = outside.
+__device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t wave, uint32_t lane, uint32_t& x, uint32_t& yl, uint32_t& gy) {
+    const uint32_t tile_y = wave / P.tiles_x, tile_x = wave - tile_y * P.tiles_x;
+    x = tile_x * 8u + (lane & 7u);
+    yl = tile_y * 8u + (lane >> 3);
+    const uint32_t band = yl / P.tile_rows;
+    gy = (P.tile_first + band * P.tile_stride) * P.tile_rows + (yl - band * P.tile_rows);
+    return x < P.cam.hsize && yl < P.out_rows && gy < P.cam.vsize;
+}
+
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
 __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -237,12 +269,8 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
     if (wave >= P.n_tiles) return;
     const KScene& sc = P.sc;
 
-    const uint32_t tile_y = wave / P.tiles_x, tile_x = wave - tile_y * P.tiles_x;
-    const uint32_t x = tile_x * 8u + (lane & 7u);
-    const uint32_t yl = tile_y * 8u + (lane >> 3);  // row in this call's packed output
-    const uint32_t band = yl / P.tile_rows;
-    const uint32_t gy = (P.tile_first + band * P.tile_stride) * P.tile_rows + (yl - band * P.tile_rows);  // global row
-    const bool valid = x < P.cam.hsize && yl < P.out_rows && gy < P.cam.vsize;
+    uint32_t x, yl, gy;
+    const bool valid = pixel_of_lane(P, wave, lane, x, yl, gy);
 
     const uint32_t pixel_key = jitter_pixel_key(P.seed, gy * P.cam.hsize + x);
     const float nlights = static_cast<float>(sc.n_lights);
@@ -262,8 +290,10 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
     int sp = 0;
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
-    __shared__ float s_park[(AREA ? 34 : 24) * 256];
+    // slot 34: the lane's jitter key (constant for the whole kernel)
+    __shared__ float s_park[(AREA ? 35 : 24) * 256];
     float* const park = s_park + threadIdx.x;
+    if (AREA) park[34 * 256] = __uint_as_float(pixel_key);
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
                        c_cells = 0, c_pattern = 0, c_container = 0;
@@ -420,8 +450,11 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 // to this light, whatever the jitter.  Streams of up to 64 records: one bit per
                 // primitive record; longer ones: nonzero = something might.  A point with none is
                 // fully lit without casting.
+                // (flat streams are short: a 32-bit mask per lane, widened for the walk, saves registers)
+                using mask_t = typename std::conditional<TREE, unsigned long long, uint32_t>::type;
+                constexpr uint32_t kTopBit = TREE ? 63u : 31u;
                 const bool by_mask = !TREE || sc.n_items <= 64u;
-                unsigned long long blockers = shades ? ~0ull : 0ull;
+                mask_t blockers = shades ? ~mask_t(0) : mask_t(0);
                 if (!(RT_EXP & 32) && wave_any(shades)) {
                     V3 lcen;
                     float lrad;
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const V3 p_over = h_over();
                     const Shaft sh = make_shaft(p_over, lcen, lrad);
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
-                    blockers = 0ull;
+                    blockers = 0;
                     traverse<TREE>(
                         sc, h_prim(), shades,
                         [&](uint32_t i, const DPrim&) {
@@ -446,11 +479,11 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
                             }
-                            if (mb) blockers |= 1ull << (prim < 63u ? prim : 63u);
+                            if (mb) blockers |= mask_t(1) << (prim < kTopBit ? prim : kTopBit);
                             return by_mask || !mb;  // without a mask the first possible blocker settles it
                         });
                 }
-                const bool open = shades && blockers == 0ull;
+                const bool open = shades && blockers == 0;
                 if (open) lit = static_cast<float>(cells);
 
                 // Phong sums over the cell centres.  Lane-local when at least half of the lanes'
@@ -486,17 +519,21 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     // the shading points ("owners") of this pass: one per slot of g lanes
                     int owner = 0;
                     uint32_t my_slot = 0, taken = 0;
-                    unsigned long long pass_mask = 0;
+                    mask_t own_mask = 0;
                     bool owner_now = false;
                     for (uint32_t k = 0; k < slots && need; ++k) {
                         const int o = __ffsll(static_cast<long long>(need)) - 1;
                         need &= need - 1ull;
-                        pass_mask |= static_cast<unsigned long long>(rl_u(static_cast<uint32_t>(blockers), o)) |
-                                     (static_cast<unsigned long long>(rl_u(static_cast<uint32_t>(blockers >> 32), o)) << 32);
+                        if (TREE)
+                            own_mask |= static_cast<mask_t>(rl_u(static_cast<uint32_t>(blockers), o)) |
+                                        static_cast<mask_t>(static_cast<unsigned long long>(rl_u(static_cast<uint32_t>(static_cast<unsigned long long>(blockers) >> 32), o)) << 32);
+                        else
+                            own_mask |= static_cast<mask_t>(rl_u(static_cast<uint32_t>(blockers), o));
                         if (slot == k) owner = o;
                         if (static_cast<int>(lane) == o) my_slot = k, owner_now = true;
                         taken = k + 1;
                     }
+                    const unsigned long long pass_mask = static_cast<unsigned long long>(own_mask);
                     const bool lane_on = slot < taken;
                     Ray sr;
                     uint32_t o_key, o_node;
@@ -507,13 +544,14 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                         const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
                         auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
                         sr.o = od3(24), sr.q = od3(27), sr.dq = od3(30), sr.self = __float_as_uint(op[33 * 256]);
+                        o_key = __float_as_uint(op[34 * 256]);
                         if (!local_phong) o_n = od3(17), o_eye = od3(20), o_shin = op[23 * 256];
                     }
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
-                        o_key = rl_u(pixel_key, os), o_node = rl_u(node, os), o_block = pass_mask != 0ull;
+                        o_node = rl_u(node, os), o_block = pass_mask != 0ull;
                     } else {
-                        o_key = shfl_u(pixel_key, owner), o_node = shfl_u(node, owner), o_block = shfl_u(blockers != 0ull ? 1u : 0u, owner) != 0u;
+                        o_node = shfl_u(node, owner), o_block = shfl_u(blockers != 0 ? 1u : 0u, owner) != 0u;
                     }
                     unsigned int my_lit = 0;
                     float my_d = 0.0f, my_s = 0.0f;
@@ -611,7 +649,8 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         }
         if (has_hit && want_refl) {
             cur.o = over;
-            cur.d = cur.d - nrm * (2.0f * dot(cur.d, nrm));  // tuple.rs:121-123
+            const V3 din = neg(eye);                     // the incoming direction, back from its parked negation
+            cur.d = din - nrm * (2.0f * dot(din, nrm));  // tuple.rs:121-123
             cur.self = hit_prim, cur.q = hq, cur.dq = hdq;
             w = w * k_refl;
             node = 2u * node + 1u;
@@ -635,9 +674,16 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         }
     }
 
-    if (valid) {
-        float* o = P.out + (static_cast<size_t>(yl) * P.cam.hsize + x) * 3u;
-        o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+    {
+        // the pixel's coordinates are worked out again rather than kept in registers (or spilled to
+        // scratch) for the whole kernel; the empty asm keeps the compiler from merging the two copies
+        uint32_t lane_again = threadIdx.x & 63u;
+        asm volatile("" : "+v"(lane_again));
+        uint32_t ox, oyl, ogy;
+        if (pixel_of_lane(P, wave, lane_again, ox, oyl, ogy)) {
+            float* o = P.out + (static_cast<size_t>(oyl) * P.cam.hsize + ox) * 3u;
+            o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+        }
     }
     if (STATS) {
         unsigned long long v[8] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container};
