@@ -7,9 +7,18 @@ A "step" is ONE FRAME of the workload: Camera::render of the scene at the config
 scene tables and output image resident in HBM.  Default workload = BASELINE.json configs[1]:
 examples/striped_sphere_multiple_lights at 1920x1080 (as the example file is written: two AREA
 lights, 8x8 and 4x4 cells, jittered with the counter RNG, seed 0).  With N > 1 (launched by
-torch.distributed.run, one rank per GPU, RCCL) the SAME frame is split into interleaved bands of 8
-pixel rows (band b -> rank b mod N), every rank renders its bands with the scene replicated, and the
-bands are gathered to rank 0 and re-interleaved there — all inside the timed region ("strong" scaling).
+torch.distributed.run, one rank per GPU) the SAME frame is split into interleaved bands of 8 pixel
+rows (band b -> rank b mod N), every rank renders its bands with the scene replicated, and the frame
+is assembled in rank 0's HBM inside the timed region ("strong" scaling):
+  * "p2p"   : rank 0 owns ONE shared frame (rt_frame_create), the other ranks map it
+              (rt_frame_open, peer access over xGMI) and their kernels store their rows straight into
+              it (RT_FLAG_GLOBAL_ROWS) — no collective and no staging copy on the data path; ranks
+              only meet at the barriers that bracket the timed region;
+  * "gather": if the shared frame cannot be set up on every rank, the packed bands go through an RCCL
+              gather to rank 0 and are re-interleaved there (the round-1 path, kept as plumbing
+              fallback — both paths run the same kernels).
+`RT_BENCH_SINGLE_DEVICE=1` (rehearsal on a one-GPU box) puts every rank on GPU 0 with a gloo control
+plane; it exercises the same inter-process frame sharing without xGMI.
 
 Rank 0 prints ONE JSON line.  `value` = unique rays traced per second over the whole job
 (primary + reflection + refraction + shadow; the reference's own count is the same for this
@@ -33,7 +42,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from raytracer_amd import ExampleScene, RtOptions, Scene  # noqa: E402
+from raytracer_amd import RT_FLAG_GLOBAL_ROWS, ExampleScene, RtOptions, Scene, SharedFrame  # noqa: E402
 from raytracer_amd import partition  # noqa: E402
 from raytracer_amd import flopmodel  # noqa: E402
 
@@ -111,14 +120,21 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
+    rehearsal = os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if rehearsal else dev  # where the control-plane tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     width, height = WORKLOADS[args.workload]
     width, height = args.width or width, args.height or height
@@ -133,29 +149,67 @@ def main():
     max_rows = partition.padded_rows(height, world)
     assert scene.output_rows(ex.camera_desc, opt) <= max_rows
     local = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
+
+    # Frame assembly for N > 1: one shared frame in rank 0's HBM, or the gather fallback.
+    shared = None
+    mode = "single"
+    if world > 1:
+        mode = "p2p"
+        box = [None, None]
+        if rank == 0:
+            try:
+                shared = SharedFrame(height, width, local_rank)
+                box = [shared.handle, local_rank]
+            except Exception as e:  # noqa: BLE001 - any failure means: use the gather path
+                print(f"bench.py: shared frame not available on rank 0 ({e})", file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        ok = 1
+        if box[0] is None:
+            ok = 0
+        elif rank != 0:
+            try:
+                shared = SharedFrame(height, width, local_rank, owner_device=box[1], handle=box[0])
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: rank {rank} cannot map the shared frame ({e})", file=sys.stderr)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            mode = "gather"
+            if shared is not None:
+                shared.close()
+                shared = None
+    opt_frame = opt
+    if mode == "p2p":
+        opt_frame = partition.rank_options(base, rank, world)
+        opt_frame.flags = RT_FLAG_GLOBAL_ROWS
     final = perm = gathered = None
-    if world > 1 and rank == 0:
+    if mode == "gather" and rank == 0:
         gathered = [torch.empty_like(local) for _ in range(world)]
         perm = torch.from_numpy(partition.gather_permutation(height, world)).to(dev)
         final = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
 
     def frame():
         stream = torch.cuda.current_stream().cuda_stream
+        if mode == "p2p":
+            scene.render_device(ex.camera_desc, shared.ptr.value, opt_frame, stream)
+            return
         scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
-        if world > 1:
+        if mode == "gather":
             dist.gather(local, gathered, dst=0)
             if rank == 0:
                 torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ray / work counters of this rank's share (untimed, instrumented kernel variant)
     _, st = scene.render(ex.camera_desc, opt, stats=True)
     counts = torch.tensor([st.primary_rays, st.reflection_rays, st.refraction_rays, st.shadow_rays, st.shaded_hits,
-                           st.light_cells, st.pattern_lookups, st.container_passes], dtype=torch.int64, device=dev)
+                           st.light_cells, st.pattern_lookups, st.container_passes], dtype=torch.int64, device=ctl)
     if world > 1:
         dist.all_reduce(counts)
     names = ["primary_rays", "reflection_rays", "refraction_rays", "shadow_rays", "shaded_hits", "light_cells",
@@ -173,25 +227,35 @@ def main():
     for k in range(args.steps):
         stream = torch.cuda.current_stream().cuda_stream
         ev[k][0].record()
-        scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
+        if mode == "p2p":
+            scene.render_device(ex.camera_desc, shared.ptr.value, opt_frame, stream)
+        else:
+            scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
         ev[k][1].record()
-        if world > 1:
+        if mode == "gather":
             dist.gather(local, gathered, dst=0)
             if rank == 0:
                 torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
     sync_all()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel
 
+    # the assembled frame must be the frame one GPU renders alone, bit for bit (untimed check)
+    verified = None
+    if world > 1 and rank == 0:
+        whole, _ = scene.render(ex.camera_desc, base)
+        got = shared.download() if mode == "p2p" else final.cpu().numpy()
+        verified = bool(np.array_equal(whole, got))
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        base, ost = (None, None)
+        cpu, ost = (None, None)
         if world == 1 and not args.no_cpu_baseline:
-            base, ost = cpu_baseline(args.workload, width, height, opt.jitter_mode, opt.seed, args.cpu_seconds)
+            cpu, ost = cpu_baseline(args.workload, width, height, opt.jitter_mode, opt.seed, args.cpu_seconds)
         cost = flopmodel.ray_cost(ex.scene_desc, ost)
         flops = flopmodel.frame_flops(mine, n_lights, cost)  # rank 0's launch
         achieved = flops / (kernel_ms * 1e-3) / 1e12
@@ -209,8 +273,11 @@ def main():
             "config": {
                 "workload": f"examples/{args.workload} at {width}x{height}, jitter={args.jitter} seed={args.seed}, "
                             f"RECURSION_DEPTH=5",
-                "partition": "whole frame on one GPU" if world == 1 else
-                             f"interleaved {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0",
+                "partition": "whole frame on one GPU" if world == 1 else (
+                    f"interleaved {BAND_ROWS}-row bands over {world} GPUs, every rank's kernel stores its rows straight "
+                    f"into ONE frame in rank 0's HBM (peer access over xGMI, no collective)" if mode == "p2p" else
+                    f"interleaved {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"),
+                "assembly": mode, "assembled_frame_equals_single_gpu_frame": verified,
                 "rays_per_frame": total_rays, "rays_by_kind": total,
             },
             "frame_ms": ms_per_step,
@@ -226,11 +293,16 @@ def main():
                 "kernel": "render_kernel<false, false, false, true>", "kernel_ms": kernel_ms,
             },
         }
-        if base is not None:
-            out["cpu_baseline"] = base
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
+        sync_all()
+        if shared is not None and rank != 0:
+            shared.close()
         dist.barrier()
+        if shared is not None and rank == 0:
+            shared.close()
         dist.destroy_process_group()
 
 

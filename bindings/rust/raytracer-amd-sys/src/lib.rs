@@ -126,4 +126,18 @@ extern "C" {
     ) -> c_int;
     pub fn rt_quantize_u8_device(rgb_device: *const f32, n: usize, out_device: *mut u8, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_quantize_u8(rgb_host: *const f32, n: usize, out_host: *mut u8) -> c_int;
+    // one frame shared by the GPUs of a node (rt_options.flags = RT_FLAG_GLOBAL_ROWS)
+    pub fn rt_frame_create(device: c_int, bytes: usize, frame_out: *mut *mut c_void, handle_out: *mut rt_ipc_handle) -> c_int;
+    pub fn rt_frame_open(device: c_int, owner_device: c_int, handle: *const rt_ipc_handle, frame_out: *mut *mut c_void) -> c_int;
+    pub fn rt_frame_close(device: c_int, frame: *mut c_void) -> c_int;
+    pub fn rt_frame_destroy(device: c_int, frame: *mut c_void) -> c_int;
+    pub fn rt_frame_download(device: c_int, frame: *const c_void, host_out: *mut c_void, bytes: usize) -> c_int;
+}
+
+pub const RT_FLAG_GLOBAL_ROWS: u32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rt_ipc_handle {
+    pub bytes: [u8; 64],
 }

@@ -125,8 +125,16 @@ typedef struct rt_options {
     uint32_t jitter_mode;          /* RT_JITTER_*                                                    */
     uint32_t seed;
     uint32_t tile_rows, tile_first, tile_stride;
-    uint32_t flags;                /* reserved, must be 0                                            */
+    uint32_t flags;                /* RT_FLAG_* bits; unknown bits are rejected                      */
 } rt_options;
+
+/* rt_render_device only: rgb_out_device is a FULL frame (vsize * hsize * 3 floats) and every row is
+ * stored at its GLOBAL position instead of packed band after band.  With a frame that lives on
+ * another GPU of the node (rt_frame_open) the ranks of a row-band partition write their bands
+ * straight into the root GPU's frame over xGMI: the "final gather" of the partition
+ * (camera.rs:183-205 collects rows through a Mutex<Canvas>) without a collective and without a
+ * staging copy. */
+#define RT_FLAG_GLOBAL_ROWS 1u
 
 /* Ray and work counters of one render (unique rays actually traced; the reference-equivalent
  * count, which re-traces the recursion once per light, is derived by the caller). */
@@ -172,6 +180,29 @@ int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_opti
  * saturate to 0..255, NaN -> 0.  n = number of floats. */
 int rt_quantize_u8_device(const float* rgb_device, size_t n, uint8_t* out_device, int device, void* stream);
 int rt_quantize_u8(const float* rgb_host, size_t n, uint8_t* out_host);
+
+/* One frame shared by the GPUs of a node (no counterpart in the reference, whose threads share one
+ * Canvas behind a Mutex, camera.rs:176,199-201: this is that shared Canvas for one process per GPU).
+ *   rt_frame_create : allocates `bytes` of device memory on `device` and exports an inter-process
+ *                     handle for it (hipIpcGetMemHandle).
+ *   rt_frame_open   : in ANOTHER process, maps that memory for kernels running on `device`
+ *                     (`owner_device` = the HIP ordinal the frame lives on; peer access over xGMI
+ *                     is enabled when the two differ).  The pointer is valid for rt_render_device
+ *                     with RT_FLAG_GLOBAL_ROWS and for rt_frame_download.
+ *   rt_frame_close  : unmaps a pointer obtained from rt_frame_open.
+ *   rt_frame_destroy: frees a frame obtained from rt_frame_create (after every opener has closed).
+ *   rt_frame_download: copies `bytes` from a frame (created or opened) to host memory, after
+ *                     waiting for the device.
+ * The caller orders the writers and the reader (e.g. a barrier between the last render and the
+ * download); rows written by different ranks never overlap. */
+typedef struct rt_ipc_handle {
+    unsigned char bytes[64];
+} rt_ipc_handle;
+int rt_frame_create(int device, size_t bytes, void** frame_out, rt_ipc_handle* handle_out);
+int rt_frame_open(int device, int owner_device, const rt_ipc_handle* handle, void** frame_out);
+int rt_frame_close(int device, void* frame);
+int rt_frame_destroy(int device, void* frame);
+int rt_frame_download(int device, const void* frame, void* host_out, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ ctypes binding used by ``bench.py``, ``__graft_entry__.py`` and the tests; it co
 and no CPU fallback: if the HIP library is missing, importing :mod:`raytracer_amd.capi` raises.
 """
 from .capi import (  # noqa: F401
+    RT_FLAG_GLOBAL_ROWS,
     ExampleScene,
     RtCameraDesc,
     RtError,
@@ -14,6 +15,7 @@ from .capi import (  # noqa: F401
     RtSceneDesc,
     RtStats,
     Scene,
+    SharedFrame,
     band_rows,
     example_names,
     lib,
@@ -23,6 +25,6 @@ from .capi import (  # noqa: F401
 )
 
 __all__ = [
-    "ExampleScene", "RtCameraDesc", "RtError", "RtOptions", "RtSceneDesc", "RtStats", "Scene",
-    "band_rows", "example_names", "lib", "lib_path", "quantize_u8", "scenes_lib",
+    "RT_FLAG_GLOBAL_ROWS", "ExampleScene", "RtCameraDesc", "RtError", "RtOptions", "RtSceneDesc", "RtStats", "Scene",
+    "SharedFrame", "band_rows", "example_names", "lib", "lib_path", "quantize_u8", "scenes_lib",
 ]

@@ -71,7 +71,7 @@ class RtStats(C.Structure):
 RT_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
     "rt_output_rows", "rt_render_device", "rt_render", "rt_render_stats", "rt_quantize_u8_device",
-    "rt_quantize_u8",
+    "rt_quantize_u8", "rt_frame_create", "rt_frame_open", "rt_frame_close", "rt_frame_destroy", "rt_frame_download",
 ]
 
 
@@ -105,6 +105,11 @@ def lib() -> C.CDLL:
         L.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
         L.rt_quantize_u8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_quantize_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rt_frame_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]
+        L.rt_frame_open.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_frame_close.argtypes = [C.c_int, C.c_void_p]
+        L.rt_frame_destroy.argtypes = [C.c_int, C.c_void_p]
+        L.rt_frame_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -222,6 +227,43 @@ def band_rows(vsize: int, tile_rows: int, tile_first: int = 0, tile_stride: int 
         rows.extend(range(b * tile_rows, min((b + 1) * tile_rows, vsize)))
         b += tile_stride
     return np.asarray(rows, dtype=np.int64)
+
+
+RT_FLAG_GLOBAL_ROWS = 1
+
+
+class SharedFrame:
+    """One full frame (height x width x 3 f32) in the HBM of ONE GPU that the other ranks of a node
+    write their row bands into directly (rt_frame_* in include/rt_amd.h; rt_render_device with
+    RT_FLAG_GLOBAL_ROWS).  The owner creates it and hands `handle` (64 bytes) to the other processes,
+    which open it; nothing here is a collective."""
+
+    def __init__(self, height: int, width: int, device: int, owner_device: Optional[int] = None,
+                 handle: Optional[bytes] = None):
+        self.height, self.width, self.device = height, width, device
+        self.nbytes = height * width * 3 * 4
+        self.ptr = C.c_void_p()
+        self.owner = handle is None
+        if self.owner:
+            h = (C.c_ubyte * 64)()
+            _check(lib().rt_frame_create(device, self.nbytes, C.byref(self.ptr), C.cast(h, C.c_void_p)))
+            self.handle = bytes(h)
+        else:
+            assert owner_device is not None and len(handle) == 64
+            self.handle = handle
+            h = (C.c_ubyte * 64).from_buffer_copy(handle)
+            _check(lib().rt_frame_open(device, owner_device, C.cast(h, C.c_void_p), C.byref(self.ptr)))
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        _check(lib().rt_frame_download(self.device, self.ptr, out.ctypes.data_as(C.c_void_p), self.nbytes))
+        return out
+
+    def close(self) -> None:
+        if self.ptr:
+            L = lib()
+            _check(L.rt_frame_destroy(self.device, self.ptr) if self.owner else L.rt_frame_close(self.device, self.ptr))
+            self.ptr = C.c_void_p()
 
 
 def quantize_u8(rgb: np.ndarray) -> np.ndarray:

@@ -47,6 +47,7 @@ int upload(const std::vector<T>& v, const T** out, std::vector<void*>& owned) {
 
 struct RenderPlan {
     uint32_t max_depth, tile_rows, tile_first, tile_stride, out_rows;
+    bool global_rows;
 };
 
 int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp) {
@@ -55,7 +56,8 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
     if (static_cast<uint64_t>(cam->hsize) * cam->vsize > 0x7FFFFFFFull) return fail(RT_ERR_CAPACITY, "image too large");
     rt_options o{};
     if (opt) o = *opt;
-    if (o.flags != 0) return fail(RT_ERR_BAD_ARGUMENT, "options.flags must be 0");
+    if (o.flags & ~RT_FLAG_GLOBAL_ROWS) return fail(RT_ERR_BAD_ARGUMENT, "options.flags holds an unknown bit");
+    rp.global_rows = (o.flags & RT_FLAG_GLOBAL_ROWS) != 0;
     if (o.jitter_mode > RT_JITTER_COUNTER) return fail(RT_ERR_UNSUPPORTED, "unknown jitter mode");
     rp.max_depth = o.max_depth ? o.max_depth : 5u;
     if (rp.max_depth > RT_MAX_DEPTH) return fail(RT_ERR_CAPACITY, "max_depth exceeds RT_MAX_DEPTH");
@@ -104,6 +106,7 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.seed = opt ? opt->seed : 0u;
     P.tile_rows = rp.tile_rows, P.tile_first = rp.tile_first, P.tile_stride = rp.tile_stride;
     P.out_rows = rp.out_rows;
+    P.global_rows = rp.global_rows ? 1u : 0u;
     P.tiles_x = (cam->hsize + 7u) / 8u;
     const uint32_t tiles_y = (rp.out_rows + 7u) / 8u;
     P.n_tiles = P.tiles_x * tiles_y;
@@ -133,6 +136,7 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
     int rc = plan_render(camera, options, rp);
     if (rc != RT_OK) return rc;
     if (!rgb_out_host && !stats) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
+    if (rp.global_rows) return fail(RT_ERR_BAD_ARGUMENT, "RT_FLAG_GLOBAL_ROWS is for rt_render_device only");
     HIP_TRY(hipSetDevice(scene->device));
     const size_t n = static_cast<size_t>(rp.out_rows) * camera->hsize * 3u;
     float* d_out = nullptr;
@@ -307,6 +311,68 @@ int rt_quantize_u8(const float* rgb_host, size_t n, uint8_t* out_host) {
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     return rc;
+}
+
+// ---------------------------------------------------------------- one frame shared across processes
+static_assert(sizeof(hipIpcMemHandle_t) == sizeof(rt_ipc_handle), "rt_ipc_handle must hold a hipIpcMemHandle_t");
+
+int rt_frame_create(int device, size_t bytes, void** frame_out, rt_ipc_handle* handle_out) {
+    if (!frame_out || !handle_out || bytes == 0) return fail(RT_ERR_BAD_ARGUMENT, "rt_frame_create: null argument or zero size");
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return hip_fail(e, "hipIpcGetMemHandle");
+    }
+    std::memcpy(handle_out->bytes, &h, sizeof(h));
+    *frame_out = p;
+    return RT_OK;
+}
+
+int rt_frame_open(int device, int owner_device, const rt_ipc_handle* handle, void** frame_out) {
+    if (!handle || !frame_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_frame_open: null argument");
+    HIP_TRY(hipSetDevice(device));
+    if (owner_device != device) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, device, owner_device));
+        if (!can) return fail(RT_ERR_UNSUPPORTED, "rt_frame_open: no peer access between the two devices");
+        hipError_t pe = hipDeviceEnablePeerAccess(owner_device, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return hip_fail(pe, "hipDeviceEnablePeerAccess");
+        (void)hipGetLastError();  // "already enabled" is sticky otherwise
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle->bytes, sizeof(h));
+    void* p = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *frame_out = p;
+    return RT_OK;
+}
+
+int rt_frame_close(int device, void* frame) {
+    if (!frame) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipIpcCloseMemHandle(frame));
+    return RT_OK;
+}
+
+int rt_frame_destroy(int device, void* frame) {
+    if (!frame) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(frame));
+    return RT_OK;
+}
+
+int rt_frame_download(int device, const void* frame, void* host_out, size_t bytes) {
+    if (!frame || !host_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_frame_download: null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, frame, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 }  // extern "C"

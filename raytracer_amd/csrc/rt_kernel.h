@@ -70,6 +70,7 @@ struct KParams {
     uint32_t max_depth, jitter_mode, seed;
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
+    uint32_t global_rows;  // RT_FLAG_GLOBAL_ROWS: `out` is a full frame, rows go to their global position
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
         asm volatile("" : "+v"(lane_again));
         uint32_t ox, oyl, ogy;
         if (pixel_of_lane(P, wave, lane_again, ox, oyl, ogy)) {
-            float* o = P.out + (static_cast<size_t>(oyl) * P.cam.hsize + ox) * 3u;
+            float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }

@@ -79,7 +79,7 @@ def test_option_and_camera_validation():
     o.tile_rows, o.tile_first, o.tile_stride = 8, 2, 2
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     o = RtOptions()
-    o.flags = 1
+    o.flags = 2  # an unknown bit (1 = RT_FLAG_GLOBAL_ROWS)
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     assert L.rt_output_rows(None, None, C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     assert L.rt_render(None, C.byref(cam), None, None, None) == RT_ERR_BAD_ARGUMENT

@@ -268,3 +268,41 @@ def test_random_area_light_scenes_match_the_scalar_spec(kind):
         dd = np.abs(gpu - sim).max(axis=-1)
         worst = max(worst, float((dd > 1e-5).mean()))
         assert np.median(dd) <= 1e-6 and (dd > 1e-5).mean() <= 6e-3, (kind, seed, float(dd.max()), float((dd > 1e-5).mean()))
+
+
+def test_global_rows_flag_assembles_the_frame_in_place():
+    """RT_FLAG_GLOBAL_ROWS: the bands of a row partition land at their global rows of ONE full frame."""
+    import torch
+    from raytracer_amd import RT_FLAG_GLOBAL_ROWS, partition
+    ex = ExampleScene("glass_sphere_checkered_floor_aerial_view", 200, 117)  # 117 rows: a ragged last band
+    sc = Scene(ex.scene_desc, 0)
+    base = RtOptions()
+    base.jitter_mode, base.seed = 1, 9
+    whole, _ = sc.render(ex.camera_desc, base)
+    frame = torch.full((117, 200, 3), -1.0, dtype=torch.float32, device="cuda:0")
+    for r in range(3):
+        o = partition.rank_options(base, r, 3)
+        o.flags = RT_FLAG_GLOBAL_ROWS
+        sc.render_device(ex.camera_desc, frame.data_ptr(), o, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), whole)
+    o = partition.rank_options(base, 0, 3)
+    o.flags = RT_FLAG_GLOBAL_ROWS
+    with pytest.raises(capi.RtError):  # host-output entry points pack their rows
+        sc.render(ex.camera_desc, o)
+    o.flags = 2
+    with pytest.raises(capi.RtError):
+        sc.render_device(ex.camera_desc, frame.data_ptr(), o, 0)
+    sc.close()
+
+
+def test_shared_frame_across_processes():
+    """rt_frame_create / rt_frame_open: other PROCESSES render their bands straight into the first
+    process's frame (the multi-GPU assembly path of bench.py).  Runs tests/shared_frame_demo.py in fresh
+    interpreters, the way bench.py's ranks start; all of them use GPU 0, the only one on the box, so the
+    inter-process mapping is exercised and xGMI is not."""
+    import subprocess
+    import sys
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shared_frame_demo.py")
+    r = subprocess.run([sys.executable, demo], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-500:])
