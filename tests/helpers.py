@@ -120,3 +120,46 @@ def compare(test: np.ndarray, ref: np.ndarray, tol: float = 1e-4) -> dict:
         "bad_frac": float(bad.mean()) if bad.size else 0.0,
         "rmse": float(np.sqrt((d ** 2).mean())) if d.size else 0.0,
     }
+
+
+def triangle_soup_desc(n: int, keep: list):
+    """rt_scene_desc of a floor plus n small random triangles (three materials, one point light).
+    `keep` receives the numpy arrays the description points into."""
+    rng = np.random.default_rng(42)
+    c = rng.uniform(-6, 6, (n, 3)) * np.array([1.0, 0.35, 1.0]) + np.array([0.0, 2.2, 0.0])
+    e0 = rng.normal(size=(n, 3)) * 0.12
+    e1 = rng.normal(size=(n, 3)) * 0.12
+    nrm = np.cross(e0, e1)  # triangle.rs:82-83: normal = e1 x e0 normalised; the sign only flips shading
+    nrm = -nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    params = np.zeros((n + 1, 24), dtype=np.float32)
+    params[1:, 0:3], params[1:, 3:6], params[1:, 6:9], params[1:, 9:12] = c, e0, e1, nrm
+    types = np.full(n + 1, 4, dtype=np.uint8)
+    types[0] = 1  # the floor
+    inv = np.tile(np.eye(4)[:3, :].reshape(12), (n + 1, 1)).astype(np.float32)
+    mats = (np.arange(n + 1) % 3).astype(np.uint32)
+    mat_param = np.array([[0.1, 0.9, 0.3, 50, 1.0, 0.0, 0.0, 0], [0.1, 0.7, 0.2, 10, 1.0, 0.2, 0.0, 0],
+                          [0.2, 0.8, 0.9, 300, 1.0, 0.0, 0.0, 0]], dtype=np.float32)
+    mat_pat = np.arange(3, dtype=np.uint32)
+    pat_type = np.zeros(3, dtype=np.uint8)
+    pat_a = np.array([[0.9, 0.9, 0.9], [0.8, 0.3, 0.2], [0.2, 0.5, 0.9]], dtype=np.float32)
+    pat_inv = np.tile(np.eye(4)[:3, :].reshape(12), (3, 1)).astype(np.float32)
+    l_type = np.zeros(1, dtype=np.uint8)
+    l_pos = np.array([[-8.0, 12.0, 6.0]], dtype=np.float32)
+    l_vec = np.zeros((1, 3), dtype=np.float32)
+    l_steps = np.ones(1, dtype=np.uint32)
+    l_col = np.ones((1, 3), dtype=np.float32)
+    ref, nxt = np.arange(n + 1, dtype=np.uint32), np.arange(1, n + 2, dtype=np.uint32)
+    from raytracer_amd import RtSceneDesc
+    d = RtSceneDesc()
+    d.abi_version = 1
+    d.n_prims, d.prim_type, d.prim_inv = n + 1, types.ctypes.data, inv.ctypes.data
+    d.prim_material, d.prim_param = mats.ctypes.data, params.ctypes.data
+    d.n_items, d.item_ref, d.item_next = n + 1, ref.ctypes.data, nxt.ctypes.data
+    d.n_materials, d.mat_param, d.mat_pattern = 3, mat_param.ctypes.data, mat_pat.ctypes.data
+    d.n_patterns, d.pat_type, d.pat_color_a = 3, pat_type.ctypes.data, pat_a.ctypes.data
+    d.pat_color_b, d.pat_inv = pat_a.ctypes.data, pat_inv.ctypes.data
+    d.n_lights, d.light_type, d.light_pos = 1, l_type.ctypes.data, l_pos.ctypes.data
+    d.light_uvec, d.light_vvec = l_vec.ctypes.data, l_vec.ctypes.data
+    d.light_usteps, d.light_vsteps, d.light_color = l_steps.ctypes.data, l_steps.ctypes.data, l_col.ctypes.data
+    keep += [params, types, inv, mats, mat_param, mat_pat, pat_type, pat_a, pat_inv, l_type, l_pos, l_vec, l_steps, l_col, ref, nxt]
+    return d

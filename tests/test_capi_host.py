@@ -206,3 +206,19 @@ def test_camera_desc_matches_the_reference_camera_tests():
 def test_unknown_scene_is_an_error():
     with pytest.raises(capi.RtError):
         ExampleScene("no_such_scene", 8, 8)
+
+
+def test_shared_frame_entry_points_validate_their_arguments():
+    L = lib()
+    frame = C.c_void_p()
+    handle = (C.c_ubyte * 64)()
+    assert L.rt_frame_create(0, 0, C.byref(frame), C.cast(handle, C.c_void_p)) == RT_ERR_BAD_ARGUMENT  # zero size
+    assert L.rt_frame_create(0, 1024, None, C.cast(handle, C.c_void_p)) == RT_ERR_BAD_ARGUMENT
+    assert L.rt_frame_open(0, 0, None, C.byref(frame)) == RT_ERR_BAD_ARGUMENT
+    assert L.rt_frame_download(0, None, None, 16) == RT_ERR_BAD_ARGUMENT
+    assert L.rt_frame_close(0, None) == 0 and L.rt_frame_destroy(0, None) == 0  # nothing to do
+    # the GLOBAL_ROWS flag belongs to rt_render_device; the host-output entry points pack their rows
+    from raytracer_amd import RT_FLAG_GLOBAL_ROWS
+    assert RT_FLAG_GLOBAL_ROWS == 1
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    assert "#define RT_FLAG_GLOBAL_ROWS 1u" in header
