@@ -14,7 +14,12 @@
 //              a transparent material — done BEFORE shading so that the ray's origin and self data
 //              are dead while the (register-hungry) shading loops run.
 //   shade      per light (world.rs:43-58).  Point light: one any-hit shadow ray per lane.  AREA
-//              light, two independent parts:
+//              light, three parts:
+//                shafts       each lane tests the shaft from ITS shading point to the light
+//                             (rt_math.h "Shafts") against the stream: records that provably stay
+//                             outside cannot occlude whatever the jitter.  No possible blocker: the
+//                             point is fully lit without casting; otherwise the survivors form a
+//                             record mask (streams of <= 64 records) for the passes below.
 //                visibility   wave-cooperative: the wave's shading points are taken one (>= 64
 //                             cells) or several (16 cells: four) at a time, ONE LIGHT CELL PER LANE;
 //                             the shadow rays of a pass leave the same point (coherent, they exit

@@ -70,6 +70,10 @@ def random_scene(rng, n_objects, keep):
         wall[:3, :3] = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]])
         wall[2, 3] = -6.0
         types.append(1), invs.append(np.linalg.inv(wall)), params.append(np.zeros(24)), mats.append(1)
+    if rng.random() < 0.4:  # a tilted, scaled plane somewhere behind the objects (row norm != 1)
+        f = _affine(rng, big=True)
+        f[:3, 3] = np.array([rng.uniform(-2, 2), rng.uniform(-1.0, 0.5), rng.uniform(-9, -5)])
+        types.append(1), invs.append(np.linalg.inv(f)), params.append(np.zeros(24)), mats.append(3)
     for _ in range(n_objects):
         t = int(rng.choice([0, 0, 2, 2, 3]))
         f = _affine(rng, big=rng.random() < 0.2)
@@ -128,7 +132,7 @@ def random_scene(rng, n_objects, keep):
 def test_no_occluder_is_ruled_out_in_random_scenes(n_objects):
     cam = ExampleScene("striped_sphere_multiple_lights", 40, 24)  # eye (0, 3, 5) looking at (0, 1, 0)
     tot = dict(pairs=0, ruled_out=0, open=0, violations=0)
-    for seed in range(6):
+    for seed in range(16):
         rng = np.random.default_rng(1000 * n_objects + seed)
         keep = []
         d = random_scene(rng, n_objects, keep)
