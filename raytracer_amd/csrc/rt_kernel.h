@@ -498,17 +498,12 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
                 if (local_phong && !(RT_EXP & 2)) {
                     const PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
-                    for (uint32_t c = 0; c < cells; ++c) {
-                        V3 centre;
-                        if (c < 64u) {
-                            centre = rl_v3(centre0, static_cast<int>(c));
-                        } else {
-                            const uint32_t cv = c / l.usteps, cu = c - cv * l.usteps;
-                            centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
-                        }
-                        float ldn = 0.0f, spec = 0.0f;
-                        if (shades) phong_cell(pp, centre, ldn, spec);
-                        sum_d += ldn, sum_s += spec;
+                    // rows of the light's grid, cells in the reference's order (material.rs:133-136)
+                    const PhongGrid pg = phong_grid(pp, l);
+                    for (uint32_t cv = 0; cv < l.vsteps; ++cv) {
+                        const PhongRow row = phong_row(pg, static_cast<float>(cv));
+                        for (uint32_t cu = 0; cu < l.usteps; ++cu)
+                            if (shades) phong_grid_cell(pp, pg, row, static_cast<float>(cu), sum_d, sum_s);
                     }
                     if (STATS && shades) c_cells += cells;
                     // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums

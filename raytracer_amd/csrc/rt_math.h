@@ -697,6 +697,19 @@ RT_HD PhongPoint phong_point(V3 p, V3 n, V3 eye, float shininess) {
     q.gate = shininess > 0.0f ? exp2f(-36.0f / shininess) : 0.0f;
     return q;
 }
+// (reflect . eye)^shininess inside a highlight; lv = cell - point, inv = 1/|lv|.
+// x^200 turns the 1e-7 absolute rounding error of an FP32 dot product of two unit vectors into 2e-5
+// RELATIVE error on highlights whose value exceeds 1, so cos(theta) is taken from the cross product
+// instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full relative accuracy in (1 - cos), and the
+// power is exp(shininess/2 * log1p(-sin^2)).
+RT_HD float phong_highlight(const PhongPoint& q, V3 lv, float inv) {
+    V3 ml = neg(lv * inv);
+    V3 rv = ml - q.n * 2.0f * dot(ml, q.n);
+    V3 cx = cross_exact(rv, q.eye);
+    float sin2 = fminf(div_f(dot(cx, cx), dot(rv, rv) * dot(q.eye, q.eye)), 1.0f);
+    if (sin2 < 0.25f) return expf(0.5f * q.shininess * log1pf(-sin2));
+    return powf(dot(rv, q.eye), q.shininess);
+}
 RT_HD void phong_cell(const PhongPoint& q, V3 cell, float& ldn_out, float& spec_out) {
     V3 lv = cell - q.p;
     float len2 = dot(lv, lv);
@@ -712,20 +725,52 @@ RT_HD void phong_cell(const PhongPoint& q, V3 cell, float& ldn_out, float& spec_
         // is below 2^-36 and is dropped (1e-11 of a colour unit) — most cells of most shading points,
         // so the wave usually skips the power altogether.
         float rde_fast = fmaf(2.0f * ldn, q.n_eye, -(dot(lv, q.eye) * inv));
-        if (rde_fast > q.gate) {
-            // x^200 turns the 1e-7 absolute rounding error of an FP32 dot product of two unit
-            // vectors into 2e-5 RELATIVE error on highlights whose value exceeds 1, so cos(theta) is
-            // taken from the cross product instead: sin^2 = |r x e|^2 / (|r|^2 |e|^2) keeps full
-            // relative accuracy in (1 - cos), and the power is exp(shininess/2 * log1p(-sin^2)).
-            V3 ml = neg(lv * inv);
-            V3 rv = ml - q.n * 2.0f * dot(ml, q.n);
-            V3 cx = cross_exact(rv, q.eye);
-            float sin2 = fminf(div_f(dot(cx, cx), dot(rv, rv) * dot(q.eye, q.eye)), 1.0f);
-            if (sin2 < 0.25f)
-                spec_out = expf(0.5f * q.shininess * log1pf(-sin2));
-            else
-                spec_out = powf(dot(rv, q.eye), q.shininess);
-        }
+        if (rde_fast > q.gate) spec_out = phong_highlight(q, lv, inv);
+    }
+}
+
+// The same sums over ALL cell centres of an area light (material.rs:133-161 with light.rs:192-216's
+// grid): centre(cu, cv) - p = a + cu u + cv v, so the three quantities a cell needs — |lv|^2, lv.n,
+// lv.eye — are a quadratic and two linear forms in (cu, cv) whose coefficients depend on the
+// shading point only.  A cell then costs six FMAs instead of forming the vector and three dot
+// products; the vector itself is only formed inside a highlight (phong_highlight, unchanged).
+struct PhongGrid {
+    V3 a, u, v;                    // lv at cell (0, 0); the per-cell steps
+    float an, un, vn;              // lv . n   = an + cu un + cv vn
+    float ae, ue, ve;              // lv . eye = ae + cu ue + cv ve
+    float aa, au2, av2, uu, vv, uv2;  // |lv|^2 = aa + cu au2 + cv av2 + cu^2 uu + cv^2 vv + cu cv uv2
+};
+RT_HD PhongGrid phong_grid(const PhongPoint& q, const DLight& l) {
+    PhongGrid g;
+    g.u = v3(l.uvec[0], l.uvec[1], l.uvec[2]), g.v = v3(l.vvec[0], l.vvec[1], l.vvec[2]);
+    g.a = (v3(l.pos[0], l.pos[1], l.pos[2]) + (g.u + g.v) * 0.5f) - q.p;
+    g.an = dot(g.a, q.n), g.un = dot(g.u, q.n), g.vn = dot(g.v, q.n);
+    g.ae = dot(g.a, q.eye), g.ue = dot(g.u, q.eye), g.ve = dot(g.v, q.eye);
+    g.aa = dot(g.a, g.a), g.au2 = 2.0f * dot(g.a, g.u), g.av2 = 2.0f * dot(g.a, g.v);
+    g.uu = dot(g.u, g.u), g.vv = dot(g.v, g.v), g.uv2 = 2.0f * dot(g.u, g.v);
+    return g;
+}
+// One row of cells (fixed cv): the row's constant parts.
+struct PhongRow {
+    float c0, c1, dn0, de0, fcv;
+};
+RT_HD PhongRow phong_row(const PhongGrid& g, float fcv) {
+    PhongRow r;
+    r.fcv = fcv;
+    r.c0 = fmaf(fcv, fmaf(fcv, g.vv, g.av2), g.aa);
+    r.c1 = fmaf(fcv, g.uv2, g.au2);
+    r.dn0 = fmaf(fcv, g.vn, g.an);
+    r.de0 = fmaf(fcv, g.ve, g.ae);
+    return r;
+}
+RT_HD void phong_grid_cell(const PhongPoint& q, const PhongGrid& g, const PhongRow& r, float fcu, float& sum_d, float& sum_s) {
+    float len2 = fmaf(fcu, fmaf(fcu, g.uu, r.c1), r.c0);
+    float inv = (len2 <= kEps * kEps) ? 0.0f : rsq_f(len2);
+    float ldn = fmaf(fcu, g.un, r.dn0) * inv;
+    if (ldn >= -kEps) {
+        sum_d += ldn;
+        float rde_fast = fmaf(2.0f * ldn, q.n_eye, -(fmaf(fcu, g.ue, r.de0) * inv));
+        if (rde_fast > q.gate) sum_s += phong_highlight(q, madd(g.u, fcu, madd(g.v, r.fcv, g.a)), inv);
     }
 }
 
