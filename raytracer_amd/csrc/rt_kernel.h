@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const V3 p_over = h_over();
                     const Shaft sh = make_shaft(p_over, lcen, lrad);
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
+                    const float p_dqy = h_dq().y;
                     blockers = 0;
                     traverse<TREE>(
                         sc, h_prim(), shades,
@@ -477,10 +478,14 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                         },
                         [&](uint32_t prim, const DPrim& p, auto self) {
                             bool mb;
-                            if (decltype(self)::value) {
+                            if (p.type == PRIM_PLANE) {
+                                // the origin's height exactly as the exact test sees it (its own plane: dq.y)
+                                const float oy = decltype(self)::value
+                                                     ? p_dqy
+                                                     : fmaf(p.inv[4], p_over.x, fmaf(p.inv[5], p_over.y, fmaf(p.inv[6], p_over.z, p.inv[7])));
+                                mb = shaft_meets_plane(sh, p.inv, oy);
+                            } else if (decltype(self)::value) {
                                 mb = p.type >= PRIM_CYLINDER || !self_clear;  // convex shapes only
-                            } else if (p.type == PRIM_PLANE) {
-                                mb = shaft_meets_plane(sh, p.inv, fmaf(p.inv[4], p_over.x, fmaf(p.inv[5], p_over.y, fmaf(p.inv[6], p_over.z, p.inv[7]))));
                             } else {
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);

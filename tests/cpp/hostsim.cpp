@@ -133,9 +133,9 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
             continue;
         }
         bool mb;
-        if (i == self) mb = r.type >= PRIM_CYLINDER || !self_clear;
-        else if (r.type == PRIM_PLANE)
-            mb = shaft_meets_plane(sh, r.inv, fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
+        if (r.type == PRIM_PLANE)
+            mb = shaft_meets_plane(sh, r.inv, i == self ? h.dq.y : fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
+        else if (i == self) mb = r.type >= PRIM_CYLINDER || !self_clear;
         else mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
         may[i] = mb;
         ++i;
