@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                             } else {
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+                                if (mb && p.type == PRIM_CUBE) mb = shaft_meets_cube(sh, p.inv);  // its three slabs
                             }
                             if (mb) blockers |= mask_t(1) << (prim < kTopBit ? prim : kTopBit);
                             return by_mask || !mb;  // without a mask the first possible blocker settles it

@@ -526,6 +526,24 @@ RT_HD bool shaft_meets_plane(const Shaft& s, const float* inv, float oy) {
     bool below = (oy < 0.0f) & (yc + reach < 0.0f);
     return !(above | below);
 }
+// Cube (cube.rs:39-122), after the ball test: the cube is the intersection of three slabs of its
+// object space.  If the apex and the whole light lie beyond the SAME face plane, every segment
+// between them does too (a half-space is convex) and misses the cube.  Same margins as the plane rule.
+RT_HD bool shaft_meets_cube(const Shaft& s, const float* inv) {
+    float l1 = fabsf(s.lc.x) + fabsf(s.lc.y) + fabsf(s.lc.z) + fabsf(s.p.x) + fabsf(s.p.y) + fabsf(s.p.z) + s.lr;
+    bool outside = false;
+    for (int k = 0; k < 3; ++k) {
+        const float* r = inv + 4 * k;
+        float pk = fmaf(r[0], s.p.x, fmaf(r[1], s.p.y, fmaf(r[2], s.p.z, r[3])));
+        float lk = fmaf(r[0], s.lc.x, fmaf(r[1], s.lc.y, fmaf(r[2], s.lc.z, r[3])));
+        float rn = sqrt_f(fmaf(r[0], r[0], fmaf(r[1], r[1], r[2] * r[2])));
+        float slack = fmaf(2e-5f, rn, 1e-4f);  // the slab distances are compared approximately (cube.rs:63-73)
+        float reach = fmaf(rn, s.lr, fmaf(1e-5f, fmaf(rn, l1, fabsf(lk)), slack));
+        float face = 1.0f + slack;
+        outside |= ((pk > face) & (lk - reach > 1.0f)) | ((pk < -face) & (lk + reach < -1.0f));
+    }
+    return !outside;
+}
 // Every ray of the shaft leaves the tangent plane at the apex on the side of the normal n: a ray
 // that starts (1e-5 outside) on a CONVEX primitive with outward normal n cannot meet it again.
 RT_HD bool shaft_leaves_surface(const Shaft& s, V3 n) { return dot(s.D, n) - s.lr > 1e-3f * (s.dlen + s.lr); }
