@@ -461,6 +461,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 constexpr uint32_t kTopBit = TREE ? 63u : 31u;
                 const bool by_mask = !TREE || sc.n_items <= 64u;
                 mask_t blockers = shades ? ~mask_t(0) : mask_t(0);
+                bool umbra = false;  // some primitive occludes every ray from this lane's point to this light
                 if (!(RT_EXP & 32) && wave_any(shades)) {
                     V3 lcen;
                     float lrad;
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const Shaft sh = make_shaft(p_over, lcen, lrad);
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
                     const float p_dqy = h_dq().y;
+                    const bool gateless = !(TREE && sc.has_gates);  // a Group's box may hide a primitive from a ray
                     blockers = 0;
                     traverse<TREE>(
                         sc, h_prim(), shades,
@@ -484,12 +486,15 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                                                      ? p_dqy
                                                      : fmaf(p.inv[4], p_over.x, fmaf(p.inv[5], p_over.y, fmaf(p.inv[6], p_over.z, p.inv[7])));
                                 mb = shaft_meets_plane(sh, p.inv, oy);
+                                if (!decltype(self)::value && mb && gateless) umbra |= shaft_blocked_by_plane(sh, p.inv, oy);
                             } else if (decltype(self)::value) {
                                 mb = p.type >= PRIM_CYLINDER || !self_clear;  // convex shapes only
                             } else {
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
                                 if (mb && p.type == PRIM_CUBE) mb = shaft_meets_cube(sh, p.inv);  // its three slabs
+                                // ... or does it occlude EVERY ray of the shaft (the point is in its umbra)?
+                                if (mb && gateless && b.r_in > 0.0f) umbra |= shaft_blocked_by_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r_in, b.r);
                             }
                             if (mb) blockers |= mask_t(1) << (prim < kTopBit ? prim : kTopBit);
                             return by_mask || !mb;  // without a mask the first possible blocker settles it
@@ -517,9 +522,10 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     // of this point cannot change the pixel.  They still count as rays of the
                     // reference's accounting (light.rs:196-208 casts them), answered without tracing.
                     const bool dark = shades && sum_d == 0.0f && sum_s == 0.0f;
-                    // likewise the rays of a point whose shaft to the light is empty (`open`)
-                    if (STATS && (dark || open)) c_shadow += cells;
-                    need &= ~__ballot(dark || open);
+                    // likewise the rays of a point whose shaft to the light is empty (`open`: lit = cells)
+                    // or wholly blocked by one primitive (`umbra`: lit = 0)
+                    if (STATS && (dark || open || umbra)) c_shadow += cells;
+                    need &= ~__ballot(dark || open || umbra);
                 }
 
                 while (need) {

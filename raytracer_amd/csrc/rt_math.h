@@ -478,9 +478,11 @@ RT_HD float container_margin(float t_hit, V3 p) {
 // jitter: the answer "not occluded" is known without casting them.  These tests only ever say
 // "cannot block" with room to spare (>= 1e-3 relative, far above FP32 rounding of the exact
 // tests); everything else is left to the exact intersection code, so the image does not change.
-struct DBound {  // 16 B per record: world-space bounding ball (r = +inf: unbounded)
-    float c[3];
+struct DBound {  // 32 B per record: world-space bounding ball (r = +inf: unbounded) and, for spheres
+    float c[3];  //  and cubes, the ball inscribed around the same centre (r_in = 0: none)
     float r;
+    float r_in;
+    float pad[3];
 };
 struct Shaft {
     V3 p, lc, D;  // apex (the over point), light ball centre, lc - p
@@ -543,6 +545,39 @@ RT_HD bool shaft_meets_cube(const Shaft& s, const float* inv) {
         outside |= ((pk > face) & (lk - reach > 1.0f)) | ((pk < -face) & (lk + reach < -1.0f));
     }
     return !outside;
+}
+// The opposite question: does a primitive occlude EVERY ray of the shaft?  Then the point is in its
+// umbra and the answer "all cells occluded" is known without casting.  Sufficient: the apex lies
+// outside a ball inscribed in the primitive, the whole primitive (bounding radius r_out) is nearer
+// than any point of the light, and the cone of directions towards the light's ball lies inside the
+// cone of directions towards the inscribed ball: theta + beta < alpha with theta = angle(e, D),
+// sin beta = lr / |D|, sin alpha = r_in / |e|.  Every such ray enters the inscribed ball ahead of the
+// apex, so it crosses the primitive's surface at some 0 < t < dist, with room to spare.
+RT_HD bool shaft_blocked_by_ball(const Shaft& s, V3 c, float r_in, float r_out) {
+    V3 e = c - s.p;
+    float de2 = dot(e, e);
+    float inv_de = rsq_f(de2);
+    float de = de2 * inv_de;
+    float sa = r_in * inv_de;
+    float inv_dl = s.dlen * s.inv_d2;
+    float ct = dot(e, s.D) * inv_de * inv_dl;
+    float st = sqrt_f(fmaxf(1.0f - ct * ct, 0.0f));
+    float cab = ct * s.cosk - st * (s.lr * inv_dl);
+    float ca = sqrt_f(fmaxf(1.0f - sa * sa, 0.0f));
+    bool ok = (r_in > 0.0f) & (sa < 0.999f) & !s.wide & (ct > 0.0f);
+    ok &= (de + r_out) < (s.dlen - s.lr) * 0.999f;
+    return ok & (cab > ca + 1e-3f);
+}
+// A plane between the apex and the whole light (plane.rs:39-51): every segment crosses it.
+RT_HD bool shaft_blocked_by_plane(const Shaft& s, const float* inv, float oy) {
+    float yc = fmaf(inv[4], s.lc.x, fmaf(inv[5], s.lc.y, fmaf(inv[6], s.lc.z, inv[7])));
+    float rn = sqrt_f(fmaf(inv[4], inv[4], fmaf(inv[5], inv[5], inv[6] * inv[6])));
+    float l1 = fabsf(s.lc.x) + fabsf(s.lc.y) + fabsf(s.lc.z) + fabsf(s.p.x) + fabsf(s.p.y) + fabsf(s.p.z) + s.lr;
+    float reach = fmaf(rn, s.lr, fmaf(1e-5f, fmaf(rn, l1, fabsf(yc)), 1e-6f));
+    float far = 1e-4f * rn * (s.dlen + s.lr);  // the crossing is well inside (0, dist) and the ray not parallel
+    bool down = (oy > far) & (yc + reach < -far);
+    bool up = (oy < -far) & (yc - reach > far);
+    return down | up;
 }
 // Every ray of the shaft leaves the tangent plane at the apex on the side of the normal n: a ray
 // that starts (1e-5 outside) on a CONVEX primitive with outward normal n cannot meet it again.

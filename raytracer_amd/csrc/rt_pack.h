@@ -185,6 +185,18 @@ inline DBound prim_world_ball(uint32_t type, const float* inv, const float* para
     if (!std::isfinite(r) || !std::isfinite(cmax)) return out;
     out.c[0] = static_cast<float>(c[0]), out.c[1] = static_cast<float>(c[1]), out.c[2] = static_cast<float>(c[2]);
     out.r = static_cast<float>(r);
+    // Inscribed ball around the same centre (spheres and cubes: the full-occlusion test of rt_math.h).
+    // Cube: the faces are the planes row_k . x = +-1, at distance 1 / |row_k| from the centre.
+    // Sphere (an ellipsoid in world space): smallest semi-axis = 1 / sigma_max(inv), bounded through
+    // Gershgorin on inv inv^T.
+    if (type == RT_PRIM_CUBE || type == RT_PRIM_SPHERE) {
+        double g[3][3], worst = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) g[i][j] = double(inv[4 * i]) * inv[4 * j] + double(inv[4 * i + 1]) * inv[4 * j + 1] + double(inv[4 * i + 2]) * inv[4 * j + 2];
+        for (int i = 0; i < 3; ++i) worst = std::max(worst, type == RT_PRIM_CUBE ? g[i][i] : std::fabs(g[i][0]) + std::fabs(g[i][1]) + std::fabs(g[i][2]));
+        const double rin = (worst > 0.0 ? 1.0 / std::sqrt(worst) : 0.0) * (1.0 - 1e-4);
+        if (std::isfinite(rin) && rin > 0.0 && rin < r) out.r_in = static_cast<float>(rin);
+    }
     return out;
 }
 // Ball around a hierarchy node's box.

@@ -113,7 +113,8 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
 // rays to the jittered point and to the four corners of every light cell: a primitive that
 // occludes one of them although it was ruled out is a violation (there must be none).
 std::atomic<bool> g_audit{false};
-std::atomic<uint64_t> g_audit_pairs{0}, g_audit_ruled_out{0}, g_audit_open{0}, g_audit_violations{0};
+std::atomic<uint64_t> g_audit_pairs{0}, g_audit_ruled_out{0}, g_audit_open{0}, g_audit_violations{0}, g_audit_umbra{0},
+    g_audit_umbra_violations{0};
 
 void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key, uint32_t node, V3 over, const HitInfo& h,
                  uint32_t self) {
@@ -125,6 +126,7 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
     const Shaft sh = make_shaft(over, lcen, lrad);
     const bool self_clear = !h.inside && shaft_leaves_surface(sh, h.n);
     uint32_t prims = 0, ruled_out = 0;
+    bool umbra = false;  // some primitive occludes EVERY ray of the shaft (rt_math.h shaft_blocked_by_*)
     for (uint32_t i = 0; i < n;) {  // the walk of rt_kernel.h, one "lane"
         const DPrim& r = s.ps.recs[i];
         const DBound& b = s.ps.bound[i];
@@ -138,7 +140,31 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
         else if (i == self) mb = r.type >= PRIM_CYLINDER || !self_clear;
         else mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r) && (r.type != PRIM_CUBE || shaft_meets_cube(sh, r.inv));
         may[i] = mb;
+        if (mb && i != self && (!s.ps.has_gates || s.ps.gate[i] == kNoGate)) {
+            if (r.type == PRIM_PLANE)
+                umbra |= shaft_blocked_by_plane(sh, r.inv, fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
+            else if (b.r_in > 0.0f)
+                umbra |= shaft_blocked_by_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r_in, b.r);
+        }
         ++i;
+    }
+    if (umbra) {  // then every ray to every cell (jittered point and corners) must be occluded
+        g_audit_umbra += 1;
+        const uint32_t ncell = l.usteps * l.vsteps;
+        for (uint32_t cell = 0; cell < ncell; ++cell) {
+            const uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
+            float ju = 0.5f, jv = 0.5f;
+            if (s.jitter_mode == RT_JITTER_COUNTER) counter_jitter(pixel_key, node, li, cell, ju, jv);
+            const float us[5] = {ju, 0.0f, 1.0f, 0.0f, 1.0f}, vs[5] = {jv, 0.0f, 0.0f, 1.0f, 1.0f};
+            for (int k = 0; k < 5; ++k) {
+                const V3 tl = point_on_light(l, cu, cv, us[k], vs[k]) - over;
+                const float dist2 = dot(tl, tl);
+                const float inv_dist = rsq_f(dist2), dist = dist2 * inv_dist;
+                Ray sr;
+                sr.o = over, sr.d = tl * inv_dist, sr.self = self, sr.q = h.q, sr.dq = h.dq;
+                if (!(dist2 > kEps * kEps) || !occluded(s, sr, dist)) g_audit_umbra_violations += 1, g_audit_violations += 1;
+            }
+        }
     }
     for (uint32_t i = 0; i < n; ++i)
         if (s.ps.recs[i].type != REC_NODE) ++prims, ruled_out += may[i] ? 0u : 1u;
@@ -325,13 +351,14 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
 
 // Renders like hostsim_render with the shaft audit switched on.  out[0] = (point, area light) pairs
 // audited, out[1] = primitives ruled out in total, out[2] = pairs with every primitive ruled out,
-// out[3] = violations.
+// out[3] = violations (both kinds), out[4] = pairs declared fully occluded, out[5] = rays of those found unoccluded.
 extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
                                    float* rgb_out, uint64_t* out, char* err_out, int err_cap) {
-    g_audit_pairs = 0, g_audit_ruled_out = 0, g_audit_open = 0, g_audit_violations = 0;
+    g_audit_pairs = 0, g_audit_ruled_out = 0, g_audit_open = 0, g_audit_violations = 0, g_audit_umbra = 0, g_audit_umbra_violations = 0;
     g_audit = true;
     const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
     g_audit = false;
     out[0] = g_audit_pairs, out[1] = g_audit_ruled_out, out[2] = g_audit_open, out[3] = g_audit_violations;
+    out[4] = g_audit_umbra, out[5] = g_audit_umbra_violations;
     return rc;
 }
