@@ -5,7 +5,9 @@ the shaft from the point to the light provably misses every primitive, and skips
 same way on flat scenes.  That is only allowed to change the speed, never the image (light.rs:196-208
 casts every ray).  The test-only host simulator evaluates the SAME rt_math.h tests at every shading
 point of a render and then tests every ruled-out primitive exactly against rays to the jittered point
-and to the four corners of every light cell: `violations` must be zero.  The `-m gpu` parity suite then
+and to the four corners of every light cell: `violations` must be zero.  The same goes for the
+opposite shortcut — a point declared to lie wholly in one primitive's umbra (all cells occluded
+without casting): every one of those rays must be occluded in the exact test.  The `-m gpu` parity suite then
 shows the images themselves unchanged against the f64 oracle.
 """
 import ctypes as C
@@ -43,6 +45,17 @@ def test_no_occluder_is_ruled_out_in_the_example_scenes(name):
     assert r["pairs"] > 0 and r["violations"] == 0, r
     # the test has teeth only if the shafts do rule things out
     assert r["ruled_out"] > 0 and r["open"] > 0, r
+
+
+@pytest.mark.parametrize("name", ["striped_sphere_multiple_lights", "glass_sphere_checkered_floor_aerial_view",
+                                  "cover_image_area"])
+def test_points_declared_fully_occluded_have_no_unoccluded_ray(name):
+    """The opposite shortcut (shaft_blocked_by_ball / _plane): a point declared to lie in a primitive's
+    umbra gets lit = 0 without casting, so EVERY ray to every cell (jittered point and corners) must be
+    occluded in the exact any-hit test."""
+    ex = ExampleScene(name, 96, 54)
+    r = audit(ex.scene_desc, ex.camera_desc, seed=2, depth=4)
+    assert r["umbra"] > 0 and r["umbra_violations"] == 0 and r["violations"] == 0, r
 
 
 def _affine(rng, big=False):
@@ -141,7 +154,7 @@ def test_no_occluder_is_ruled_out_in_random_scenes(n_objects):
         for k in tot:
             tot[k] += r[k]
     assert tot["pairs"] > 1000 and tot["violations"] == 0, tot
-    assert tot["ruled_out"] > 0, tot
+    assert tot["ruled_out"] > 0 and tot["umbra"] > 0 and tot["umbra_violations"] == 0, tot
 
 
 def many_planes_scene(rng, keep, n_planes=70):
