@@ -13,7 +13,7 @@ product: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_scenes.so
 
 $(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kernel.h raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) raytracer_amd/csrc/rt_amd.hip -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -Wl,-Bsymbolic raytracer_amd/csrc/rt_amd.hip -o $@
 
 $(LIBDIR)/librt_scenes.so: scenes/scenes_capi.cpp scenes/examples.inc include/raytracer_amd/raytracer.hpp include/raytracer_amd/png.hpp include/rt_amd.h $(LIBDIR)/librt_amd.so
 	$(CXX) $(CXXFLAGS) -shared scenes/scenes_capi.cpp -o $@ -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
@@ -24,7 +24,9 @@ oracle:
 testhelpers: tests/cpp/_build/libhostsim.so
 tests/cpp/_build/libhostsim.so: tests/cpp/hostsim.cpp raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
 	@mkdir -p tests/cpp/_build
-	$(CXX) $(CXXFLAGS) -shared tests/cpp/hostsim.cpp -o $@
+	# -Bsymbolic: the simulator must run ITS OWN copies of the inline functions of rt_math.h / rt_pack.h,
+	# not the ones exported by the product library that the same test process has loaded (RTLD_GLOBAL)
+	$(CXX) $(CXXFLAGS) -shared -Wl,-Bsymbolic tests/cpp/hostsim.cpp -o $@
 
 clean:
 	rm -rf $(LIBDIR) tests/cpp/_build
