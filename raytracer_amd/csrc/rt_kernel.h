@@ -83,6 +83,7 @@ constexpr int kStackCap = 8;  // RT_MAX_DEPTH
 // the builtin keeps the predicate as a lane mask (s_and with exec); __ballot() goes through a VGPR
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool wave_any(bool p) { return wave_ballot(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return wave_ballot(!p) == 0ull; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ uint32_t shfl_u(uint32_t v, int src) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), src, 64)); }
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 const bool by_mask = !TREE || sc.n_items <= 64u;
                 mask_t blockers = shades ? ~mask_t(0) : mask_t(0);
                 bool umbra = false;  // some primitive occludes every ray from this lane's point to this light
+                bool far_front = false, no_spec = false;  // what holds for ALL cells of this light (PhongBounds)
                 if (!(RT_EXP & 32) && wave_any(shades)) {
                     V3 lcen;
                     float lrad;
@@ -471,6 +473,10 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
                     const float p_dqy = h_dq().y;
                     const bool gateless = !(TREE && sc.has_gates);  // a Group's box may hide a primitive from a ray
+                    {
+                        const PhongBounds pb = phong_bounds(phong_point(p_over, ld3(17), ld3(20), park[23 * 256]), sh.D, sh.dlen, sh.lr, sh.cosk, sh.wide);
+                        far_front = pb.far_front, no_spec = pb.no_spec || park[13 * 256] == 0.0f;  // no specular term at all
+                    }
                     blockers = 0;
                     traverse<TREE>(
                         sc, h_prim(), shades,
@@ -508,14 +514,17 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 // (chunk 0) and is broadcast with v_readlane; summed in cell order.
                 const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
                 if (local_phong && !(RT_EXP & 2)) {
-                    const PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
-                    // rows of the light's grid, cells in the reference's order (material.rs:133-136)
+                    PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
+                    if (!shades) pp.gate = INFINITY;  // lanes without a shading point run along and are zeroed below
                     const PhongGrid pg = phong_grid(pp, l);
-                    for (uint32_t cv = 0; cv < l.vsteps; ++cv) {
-                        const PhongRow row = phong_row(pg, static_cast<float>(cv));
-                        for (uint32_t cu = 0; cu < l.usteps; ++cu)
-                            if (shades) phong_grid_cell(pp, pg, row, static_cast<float>(cu), sum_d, sum_s);
-                    }
+                    // the per-cell gates are dropped when they are known to pass (or fail) in every lane
+                    if (!wave_all(!shades || no_spec))
+                        phong_grid_sums<true, true>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                    else if (!wave_all(!shades || far_front))
+                        phong_grid_sums<true, false>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                    else
+                        phong_grid_sums<false, false>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                    if (!shades) sum_d = 0.0f, sum_s = 0.0f;
                     if (STATS && shades) c_cells += cells;
                     // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums
                     // are exactly zero and multiply the intensity (material.rs:161), so the shadow rays

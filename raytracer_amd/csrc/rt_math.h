@@ -783,47 +783,123 @@ RT_HD void phong_cell(const PhongPoint& q, V3 cell, float& ldn_out, float& spec_
 }
 
 // The same sums over ALL cell centres of an area light (material.rs:133-161 with light.rs:192-216's
-// grid): centre(cu, cv) - p = a + cu u + cv v, so the three quantities a cell needs — |lv|^2, lv.n,
-// lv.eye — are a quadratic and two linear forms in (cu, cv) whose coefficients depend on the
-// shading point only.  A cell then costs six FMAs instead of forming the vector and three dot
-// products; the vector itself is only formed inside a highlight (phong_highlight, unchanged).
+// grid): centre(cu, cv) - p = a + cu u + cv v, so the three quantities a cell needs — |lv|^2, lv.n
+// and lv.R with R = 2 (n.eye) n - eye, since (-lightv).reflect(n) . eye = lightv . R — are a quadratic
+// and two linear forms in (cu, cv) whose coefficients depend on the shading point only.  A cell then
+// costs five FMAs instead of forming the vector and three dot products; the vector itself is only
+// formed inside a highlight (phong_highlight, unchanged).
 struct PhongGrid {
     V3 a, u, v;                    // lv at cell (0, 0); the per-cell steps
-    float an, un, vn;              // lv . n   = an + cu un + cv vn
-    float ae, ue, ve;              // lv . eye = ae + cu ue + cv ve
+    float an, un, vn;              // lv . n = an + cu un + cv vn
+    float ar, ur, vr;              // lv . R = ar + cu ur + cv vr
     float aa, au2, av2, uu, vv, uv2;  // |lv|^2 = aa + cu au2 + cv av2 + cu^2 uu + cv^2 vv + cu cv uv2
 };
 RT_HD PhongGrid phong_grid(const PhongPoint& q, const DLight& l) {
     PhongGrid g;
     g.u = v3(l.uvec[0], l.uvec[1], l.uvec[2]), g.v = v3(l.vvec[0], l.vvec[1], l.vvec[2]);
     g.a = (v3(l.pos[0], l.pos[1], l.pos[2]) + (g.u + g.v) * 0.5f) - q.p;
+    const V3 R = madd(q.n, 2.0f * q.n_eye, neg(q.eye));
     g.an = dot(g.a, q.n), g.un = dot(g.u, q.n), g.vn = dot(g.v, q.n);
-    g.ae = dot(g.a, q.eye), g.ue = dot(g.u, q.eye), g.ve = dot(g.v, q.eye);
+    g.ar = dot(g.a, R), g.ur = dot(g.u, R), g.vr = dot(g.v, R);
     g.aa = dot(g.a, g.a), g.au2 = 2.0f * dot(g.a, g.u), g.av2 = 2.0f * dot(g.a, g.v);
     g.uu = dot(g.u, g.u), g.vv = dot(g.v, g.v), g.uv2 = 2.0f * dot(g.u, g.v);
     return g;
 }
-// One row of cells (fixed cv): the row's constant parts.
+// One row of cells (fixed cv) from column `base` on: the forms in k = cu - base.
 struct PhongRow {
-    float c0, c1, dn0, de0, fcv;
+    float c0, c1, dn0, dr0;
 };
 RT_HD PhongRow phong_row(const PhongGrid& g, float fcv) {
     PhongRow r;
-    r.fcv = fcv;
     r.c0 = fmaf(fcv, fmaf(fcv, g.vv, g.av2), g.aa);
     r.c1 = fmaf(fcv, g.uv2, g.au2);
     r.dn0 = fmaf(fcv, g.vn, g.an);
-    r.de0 = fmaf(fcv, g.ve, g.ae);
+    r.dr0 = fmaf(fcv, g.vr, g.ar);
     return r;
 }
-RT_HD void phong_grid_cell(const PhongPoint& q, const PhongGrid& g, const PhongRow& r, float fcu, float& sum_d, float& sum_s) {
-    float len2 = fmaf(fcu, fmaf(fcu, g.uu, r.c1), r.c0);
-    float inv = (len2 <= kEps * kEps) ? 0.0f : rsq_f(len2);
-    float ldn = fmaf(fcu, g.un, r.dn0) * inv;
-    if (ldn >= -kEps) {
+RT_HD PhongRow phong_row_from(const PhongGrid& g, const PhongRow& r, float base) {
+    PhongRow s;
+    s.c0 = fmaf(base, fmaf(base, g.uu, r.c1), r.c0);
+    s.c1 = fmaf(2.0f * base, g.uu, r.c1);
+    s.dn0 = fmaf(base, g.un, r.dn0);
+    s.dr0 = fmaf(base, g.ur, r.dr0);
+    return s;
+}
+// What is known about ALL cells of one light seen from one shading point (bounds over the ball
+// around the light, with room to spare); lets the sums run without the per-cell gates.
+//   far_front : no cell centre is within 1e-2 of the point, and every cell is in front of the surface
+//               (material.rs:145's gate passes everywhere, normalize() never fails)
+//   no_spec   : (reflect . eye) stays below the highlight gate for every cell
+struct PhongBounds {
+    bool far_front, no_spec;
+};
+RT_HD PhongBounds phong_bounds(const PhongPoint& q, V3 D, float dlen, float lr, float cosk, bool wide) {
+    PhongBounds b;
+    b.far_front = !wide & (dlen - lr > 1e-2f) & (dot(D, q.n) - lr > 1e-3f * (dlen + lr));
+    const V3 R = madd(q.n, 2.0f * q.n_eye, neg(q.eye));
+    const float r2 = dot(R, R);
+    const float rlen = r2 * rsq_f(fmaxf(r2, 1e-30f));
+    const float inv_dl = rcp_f(dlen);
+    const float ct = fminf(fmaxf(dot(D, R) * inv_dl * rsq_f(fmaxf(r2, 1e-30f)), -1.0f), 1.0f);  // cos angle(D, R)
+    const float st = sqrt_f(fmaxf(1.0f - ct * ct, 0.0f));
+    const float sb = lr * inv_dl;                                  // sin of the light ball's half angle
+    const float best = rlen * fmaf(ct, cosk, st * sb);             // |R| cos(theta - beta) when theta > beta
+    b.no_spec = !wide & (ct < cosk - 1e-3f) & (best < q.gate - 2e-3f * fmaxf(rlen, 1.0f));
+    return b;
+}
+// GATED: the per-cell gates of material.rs:145 and of normalize() are evaluated (else known to pass);
+// SPEC: a highlight is possible.  fk = cu - base of the row.
+template <bool GATED, bool SPEC>
+RT_HD void phong_grid_cell(const PhongPoint& q, const PhongGrid& g, const PhongRow& r, float fk, float base, float fcv, float& sum_d,
+                           float& sum_s) {
+    float len2 = fmaf(fk, fmaf(fk, g.uu, r.c1), r.c0);
+    float inv = (GATED && len2 <= kEps * kEps) ? 0.0f : rsq_f(len2);
+    float ldn = fmaf(fk, g.un, r.dn0) * inv;
+    if (!GATED || ldn >= -kEps) {
         sum_d += ldn;
-        float rde_fast = fmaf(2.0f * ldn, q.n_eye, -(fmaf(fcu, g.ue, r.de0) * inv));
-        if (rde_fast > q.gate) sum_s += phong_highlight(q, madd(g.u, fcu, madd(g.v, r.fcv, g.a)), inv);
+        if (SPEC) {
+            float rde_fast = fmaf(fk, g.ur, r.dr0) * inv;
+            if (rde_fast > q.gate) sum_s += phong_highlight(q, madd(g.u, base + fk, madd(g.v, fcv, g.a)), inv);
+        }
+    }
+}
+// All cells, in the reference's order (material.rs:133-136: rows of v, cells of u).  Without
+// highlights the row is straight-line code, eight cells at a time with constant indices.
+template <bool GATED, bool SPEC>
+RT_HD void phong_grid_sums(const PhongPoint& q, const PhongGrid& g, uint32_t usteps, uint32_t vsteps, float& sum_d, float& sum_s) {
+    for (uint32_t cv = 0; cv < vsteps; ++cv) {
+        const float fcv = static_cast<float>(cv);
+        const PhongRow row = phong_row(g, fcv);
+        if (SPEC) {
+            for (uint32_t cu = 0; cu < usteps; ++cu)
+                phong_grid_cell<GATED, true>(q, g, row, static_cast<float>(cu), 0.0f, fcv, sum_d, sum_s);
+        } else {
+            for (uint32_t cu = 0; cu < usteps; cu += 8u) {
+                const float base = static_cast<float>(cu);
+                const PhongRow r = cu ? phong_row_from(g, row, base) : row;
+                const uint32_t n = usteps - cu;
+                if (n >= 8u) {
+                    phong_grid_cell<GATED, false>(q, g, r, 0.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 1.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 2.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 3.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 4.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 5.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 6.0f, base, fcv, sum_d, sum_s);
+                    phong_grid_cell<GATED, false>(q, g, r, 7.0f, base, fcv, sum_d, sum_s);
+                } else {
+                    uint32_t k = 0;
+                    if (n >= 4u) {
+                        phong_grid_cell<GATED, false>(q, g, r, 0.0f, base, fcv, sum_d, sum_s);
+                        phong_grid_cell<GATED, false>(q, g, r, 1.0f, base, fcv, sum_d, sum_s);
+                        phong_grid_cell<GATED, false>(q, g, r, 2.0f, base, fcv, sum_d, sum_s);
+                        phong_grid_cell<GATED, false>(q, g, r, 3.0f, base, fcv, sum_d, sum_s);
+                        k = 4u;
+                    }
+                    for (; k < n; ++k) phong_grid_cell<GATED, false>(q, g, r, static_cast<float>(k), base, fcv, sum_d, sum_s);
+                }
+            }
+        }
     }
 }
 

@@ -114,16 +114,32 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
 // occludes one of them although it was ruled out is a violation (there must be none).
 std::atomic<bool> g_audit{false};
 std::atomic<uint64_t> g_audit_pairs{0}, g_audit_ruled_out{0}, g_audit_open{0}, g_audit_violations{0}, g_audit_umbra{0},
-    g_audit_umbra_violations{0};
+    g_audit_umbra_violations{0}, g_audit_front{0}, g_audit_dull{0}, g_audit_phong_violations{0};
 
 void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key, uint32_t node, V3 over, const HitInfo& h,
-                 uint32_t self) {
+                 uint32_t self, float shininess) {
     const uint32_t n = s.ps.n_items;
     std::vector<uint8_t> may(n, 0);
     V3 lcen;
     float lrad;
     light_ball(l, lcen, lrad);
     const Shaft sh = make_shaft(over, lcen, lrad);
+    {  // the bounds that let the kernel drop the per-cell gates of the Phong sums (rt_math.h PhongBounds):
+       // checked against the per-cell evaluation of material.rs:138-159 (phong_cell) at every cell centre
+        const PhongPoint pp = phong_point(over, h.n, h.eye, shininess);
+        const PhongBounds pb = phong_bounds(pp, sh.D, sh.dlen, sh.lr, sh.cosk, sh.wide);
+        g_audit_front += pb.far_front ? 1u : 0u, g_audit_dull += pb.no_spec ? 1u : 0u;
+        if (pb.far_front || pb.no_spec)
+            for (uint32_t cv = 0; cv < l.vsteps; ++cv)
+                for (uint32_t cu = 0; cu < l.usteps; ++cu) {
+                    const V3 centre = point_on_light(l, cu, cv, 0.5f, 0.5f);
+                    const V3 lv = centre - over;
+                    float ldn, spec;
+                    phong_cell(pp, centre, ldn, spec);
+                    if (pb.far_front && !(ldn > 0.0f && dot(lv, lv) > 1e-6f)) g_audit_phong_violations += 1;
+                    if (pb.no_spec && spec != 0.0f) g_audit_phong_violations += 1;
+                }
+    }
     const bool self_clear = !h.inside && shaft_leaves_surface(sh, h.n);
     uint32_t prims = 0, ruled_out = 0;
     bool umbra = false;  // some primitive occludes EVERY ray of the shaft (rt_math.h shaft_blocked_by_*)
@@ -227,7 +243,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
                 V3 lc = v3(l.color[0], l.color[1], l.color[2]);
                 V3 ec = pc * lc;
                 uint32_t cells = l.usteps * l.vsteps;
-                if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, c.prim);
+                if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, c.prim, m.shininess);
                 uint32_t lit = 0;
                 float sum_d = 0.0f, sum_s = 0.0f;
                 for (uint32_t cell = 0; cell < cells; ++cell) {
@@ -351,14 +367,18 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
 
 // Renders like hostsim_render with the shaft audit switched on.  out[0] = (point, area light) pairs
 // audited, out[1] = primitives ruled out in total, out[2] = pairs with every primitive ruled out,
-// out[3] = violations (both kinds), out[4] = pairs declared fully occluded, out[5] = rays of those found unoccluded.
+// out[3] = violations (both kinds), out[4] = pairs declared fully occluded, out[5] = rays of those found unoccluded,
+// out[6] = pairs whose cells are all declared far and in front, out[7] = pairs declared free of highlights,
+// out[8] = cells contradicting either declaration.
 extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
                                    float* rgb_out, uint64_t* out, char* err_out, int err_cap) {
     g_audit_pairs = 0, g_audit_ruled_out = 0, g_audit_open = 0, g_audit_violations = 0, g_audit_umbra = 0, g_audit_umbra_violations = 0;
+    g_audit_front = 0, g_audit_dull = 0, g_audit_phong_violations = 0;
     g_audit = true;
     const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
     g_audit = false;
     out[0] = g_audit_pairs, out[1] = g_audit_ruled_out, out[2] = g_audit_open, out[3] = g_audit_violations;
     out[4] = g_audit_umbra, out[5] = g_audit_umbra_violations;
+    out[6] = g_audit_front, out[7] = g_audit_dull, out[8] = g_audit_phong_violations;
     return rc;
 }
