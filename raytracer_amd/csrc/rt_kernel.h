@@ -495,6 +495,11 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                                 if (!decltype(self)::value && mb && gateless) umbra |= shaft_blocked_by_plane(sh, p.inv, oy);
                             } else if (decltype(self)::value) {
                                 mb = p.type >= PRIM_CYLINDER || !self_clear;  // convex shapes only
+                                // a point inside its own sphere or cube (hit from within), the light outside it
+                                if (hit_inside && p.type < PRIM_CYLINDER && gateless) {
+                                    const DBound b = sc.bound[prim];
+                                    umbra |= shaft_leaves_solid(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+                                }
                             } else {
                                 const DBound b = sc.bound[prim];
                                 mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
@@ -518,12 +523,13 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     if (!shades) pp.gate = INFINITY;  // lanes without a shading point run along and are zeroed below
                     const PhongGrid pg = phong_grid(pp, l);
                     // the per-cell gates are dropped when they are known to pass (or fail) in every lane
+                    const uint32_t pus = (RT_EXP & 512) ? 1u : l.usteps, pvs = (RT_EXP & 512) ? 1u : l.vsteps;
                     if (!wave_all(!shades || no_spec))
-                        phong_grid_sums<true, true>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                        phong_grid_sums<true, true>(pp, pg, pus, pvs, sum_d, sum_s);
                     else if (!wave_all(!shades || far_front))
-                        phong_grid_sums<true, false>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                        phong_grid_sums<true, false>(pp, pg, pus, pvs, sum_d, sum_s);
                     else
-                        phong_grid_sums<false, false>(pp, pg, l.usteps, l.vsteps, sum_d, sum_s);
+                        phong_grid_sums<false, false>(pp, pg, pus, pvs, sum_d, sum_s);
                     if (!shades) sum_d = 0.0f, sum_s = 0.0f;
                     if (STATS && shades) c_cells += cells;
                     // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     need &= ~__ballot(dark || open || umbra);
                 }
 
+                if (RT_EXP & 1024) need = 0;
                 while (need) {
                     // the shading points ("owners") of this pass: one per slot of g lanes
                     int owner = 0;

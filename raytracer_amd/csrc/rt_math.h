@@ -38,8 +38,10 @@ RT_HD float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
 RT_HD float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
 RT_HD float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
 RT_HD float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32; gates only, never a result
+RT_HD float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; gates only, never a result
 #else
 RT_HD float fast_log2(float x) { return log2f(x); }
+RT_HD float fast_exp2(float x) { return exp2f(x); }
 RT_HD float rcp_f(float x) { return 1.0f / x; }
 RT_HD float sqrt_f(float x) { return sqrtf(x); }
 RT_HD float rsq_f(float x) { return 1.0f / sqrtf(x); }
@@ -579,6 +581,14 @@ RT_HD bool shaft_blocked_by_plane(const Shaft& s, const float* inv, float oy) {
     bool up = (oy < -far) & (yc - reach > far);
     return down | up;
 }
+// The apex lies INSIDE a closed convex primitive (a sphere or cube whose surface was hit from within,
+// so the over point sits 1e-5 below it) and the whole light outside the primitive's bounding ball:
+// every ray of the shaft crosses the surface on its way out, before it reaches the light.
+RT_HD bool shaft_leaves_solid(const Shaft& s, V3 c, float r_out) {
+    V3 e = s.lc - c;
+    float reach = s.lr + fmaf(r_out, 1.001f, 1e-4f);
+    return dot(e, e) > reach * reach;
+}
 // Every ray of the shaft leaves the tangent plane at the apex on the side of the normal n: a ray
 // that starts (1e-5 outside) on a CONVEX primitive with outward normal n cannot meet it again.
 RT_HD bool shaft_leaves_surface(const Shaft& s, V3 n) { return dot(s.D, n) - s.lr > 1e-3f * (s.dlen + s.lr); }
@@ -747,7 +757,7 @@ RT_HD PhongPoint phong_point(V3 p, V3 n, V3 eye, float shininess) {
     PhongPoint q;
     q.p = p, q.n = n, q.eye = eye, q.shininess = shininess;
     q.n_eye = dot(n, eye);
-    q.gate = shininess > 0.0f ? exp2f(-36.0f / shininess) : 0.0f;
+    q.gate = shininess > 0.0f ? fast_exp2(-36.0f * rcp_f(shininess)) : 0.0f;  // a threshold: a few ulps are immaterial
     return q;
 }
 // (reflect . eye)^shininess inside a highlight; lv = cell - point, inv = 1/|lv|.

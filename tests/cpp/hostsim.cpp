@@ -153,7 +153,11 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
         bool mb;
         if (r.type == PRIM_PLANE)
             mb = shaft_meets_plane(sh, r.inv, i == self ? h.dq.y : fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
-        else if (i == self) mb = r.type >= PRIM_CYLINDER || !self_clear;
+        else if (i == self) {
+            mb = r.type >= PRIM_CYLINDER || !self_clear;
+            if (h.inside && r.type < PRIM_CYLINDER && (!s.ps.has_gates || s.ps.gate[i] == kNoGate))
+                umbra |= shaft_leaves_solid(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
+        }
         else mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r) && (r.type != PRIM_CUBE || shaft_meets_cube(sh, r.inv));
         may[i] = mb;
         if (mb && i != self && (!s.ps.has_gates || s.ps.gate[i] == kNoGate)) {
