@@ -464,13 +464,17 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                 mask_t blockers = shades ? ~mask_t(0) : mask_t(0);
                 bool umbra = false;  // some primitive occludes every ray from this lane's point to this light
                 bool far_front = false, no_spec = false;  // what holds for ALL cells of this light (PhongBounds)
+                unsigned long long behind_mask = 0ull;  // lanes whose light lies wholly below their tangent plane
                 if (!(RT_EXP & 32) && wave_any(shades)) {
                     V3 lcen;
                     float lrad;
                     light_ball(l, lcen, lrad);
                     const V3 p_over = h_over();
                     const Shaft sh = make_shaft(p_over, lcen, lrad);
-                    const bool self_clear = !hit_inside && shaft_leaves_surface(sh, ld3(17));
+                    const int side = shaft_side_of_surface(sh, ld3(17), l);
+                    const bool self_clear = !hit_inside && side > 0;
+                    const bool walks = shades && side >= 0;  // else: Phong sums exactly zero, nothing to find out
+                    behind_mask = wave_ballot(shades && side < 0);
                     const float p_dqy = h_dq().y;
                     const bool gateless = !(TREE && sc.has_gates);  // a Group's box may hide a primitive from a ray
                     {
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     }
                     blockers = 0;
                     traverse<TREE>(
-                        sc, h_prim(), shades,
+                        sc, h_prim(), walks,
                         [&](uint32_t i, const DPrim&) {
                             const DBound b = sc.bound[i];
                             return shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
@@ -510,15 +514,46 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                             if (mb) blockers |= mask_t(1) << (prim < kTopBit ? prim : kTopBit);
                             return by_mask || !mb;  // without a mask the first possible blocker settles it
                         });
+                    // What the balls leave undecided: the pyramid from the point to the light's
+                    // parallelogram itself, in the object space of each sphere or cube still flagged
+                    // (rt_math.h ShaftObj) — a walk of its own, over the flagged records only.
+                    if (by_mask && !(RT_EXP & 2048)) {
+                        const uint32_t self_prim = h_prim();
+                        // this lane's flagged records, without its own primitive and the shared top bit
+                        mask_t rem = blockers & ~(mask_t(1) << kTopBit);
+                        if (self_prim < kTopBit) rem &= ~(mask_t(1) << self_prim);
+                        for (;;) {
+                            if (umbra) rem = 0;
+                            const unsigned long long todo = wave_ballot(rem != 0);
+                            if (!todo) break;
+                            const int first = __ffsll(static_cast<long long>(todo)) - 1;  // some lane with work: its lowest record
+                            uint32_t i;
+                            if (TREE) {
+                                const uint32_t lo = rl_u(static_cast<uint32_t>(rem), first);
+                                const uint32_t hi = rl_u(static_cast<uint32_t>(static_cast<unsigned long long>(rem) >> 32), first);
+                                i = lo ? static_cast<uint32_t>(__builtin_ctz(lo)) : 32u + static_cast<uint32_t>(__builtin_ctz(hi));
+                            } else {
+                                i = static_cast<uint32_t>(__builtin_ctz(rl_u(static_cast<uint32_t>(rem), first)));
+                            }
+                            const bool mine = ((rem >> i) & mask_t(1)) != 0;
+                            rem &= ~(mask_t(1) << i);
+                            const DBound b = sc.bound[i];
+                            if (!(b.margin > 0.0f)) continue;  // spheres and cubes only
+                            const DPrim p = sc.recs[i];
+                            if (mine) {
+                                const ShaftObj so = shaft_in_object_space(p.inv, h_over(), l);
+                                if (pyramid_misses(so, p.type == PRIM_CUBE, b.margin)) blockers &= ~(mask_t(1) << i);
+                                else if (gateless) umbra |= pyramid_blocked(so, p.type == PRIM_CUBE, b.margin);
+                            }
+                        }
+                    }
                 }
                 const bool open = shades && blockers == 0;
                 if (open) lit = static_cast<float>(cells);
 
-                // Phong sums over the cell centres.  Lane-local when at least half of the lanes'
-                // worth of cooperative passes would be needed: cell c's centre sits in lane c
-                // (chunk 0) and is broadcast with v_readlane; summed in cell order.
-                const bool local_phong = static_cast<uint32_t>(__popcll(need)) * 2u >= cells * slots || (RT_EXP & 8);
-                if (local_phong && !(RT_EXP & 2)) {
+                // Phong sums over the cell centres, every lane for its own point, cells in the
+                // reference's order (material.rs:133-136).
+                if (wave_ballot(shades) & ~behind_mask) {  // (a tile of faces turned away from the light has nothing to sum)
                     PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
                     if (!shades) pp.gate = INFINITY;  // lanes without a shading point run along and are zeroed below
                     const PhongGrid pg = phong_grid(pp, l);
@@ -530,8 +565,10 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                         phong_grid_sums<true, false>(pp, pg, pus, pvs, sum_d, sum_s);
                     else
                         phong_grid_sums<false, false>(pp, pg, pus, pvs, sum_d, sum_s);
-                    if (!shades) sum_d = 0.0f, sum_s = 0.0f;
-                    if (STATS && shades) c_cells += cells;
+                    if (!shades || ((behind_mask >> lane) & 1ull)) sum_d = 0.0f, sum_s = 0.0f;
+                }
+                if (STATS && shades) c_cells += cells;
+                {
                     // Every cell behind the surface (material.rs:145 gates both Phong terms): the sums
                     // are exactly zero and multiply the intensity (material.rs:161), so the shadow rays
                     // of this point cannot change the pixel.  They still count as rays of the
@@ -566,24 +603,19 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
                     const bool lane_on = slot < taken;
                     Ray sr;
                     uint32_t o_key, o_node;
-                    bool o_block;
-                    V3 o_n = v3(0.0f, 0.0f, 0.0f), o_eye = v3(0.0f, 0.0f, 0.0f);
-                    float o_shin = 1.0f;
                     {  // the owner's hit data: its LDS slots, read by every lane of its group (a broadcast)
                         const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
                         auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
                         sr.o = od3(24), sr.q = od3(27), sr.dq = od3(30), sr.self = __float_as_uint(op[33 * 256]);
                         o_key = __float_as_uint(op[34 * 256]);
-                        if (!local_phong) o_n = od3(17), o_eye = od3(20), o_shin = op[23 * 256];
                     }
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
-                        o_node = rl_u(node, os), o_block = pass_mask != 0ull;
+                        o_node = rl_u(node, os);
                     } else {
-                        o_node = shfl_u(node, owner), o_block = shfl_u(blockers != 0 ? 1u : 0u, owner) != 0u;
+                        o_node = shfl_u(node, owner);
                     }
                     unsigned int my_lit = 0;
-                    float my_d = 0.0f, my_s = 0.0f;
                     for (uint32_t ch = 0; ch < chunks; ++ch) {
                         const uint32_t cell = ch * 64u + sub;
                         const bool con = lane_on && cell < cells;
@@ -608,29 +640,14 @@ __global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParam
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        // an owner with an empty shaft (it is here for its Phong cells only) casts nothing
-                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && o_block, by_mask, pass_mask);
+                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast, by_mask, pass_mask);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
-                        if (!local_phong) {  // few lanes have a hit: their Phong cells ride along, one per lane
-                            float ldn = 0.0f, spec = 0.0f;
-                            if (con) phong_cell(phong_point(sr.o, o_n, o_eye, o_shin), centre, ldn, spec);
-                            for (uint32_t s = 1; s < g; s <<= 1) {  // butterfly inside the slot's lane group
-                                ldn += __shfl_xor(ldn, static_cast<int>(s), 64);
-                                spec += __shfl_xor(spec, static_cast<int>(s), 64);
-                            }
-                            const float rd = shfl_f(ldn, lead), rs = shfl_f(spec, lead);
-                            if (owner_now) my_d += rd, my_s += rs;
-                            if (STATS && con) c_cells++;
-                        }
                         if (STATS && cast) c_shadow++;
                     }
-                    if (owner_now) {
-                        lit = static_cast<float>(my_lit);
-                        if (!local_phong) sum_d = my_d, sum_s = my_s;
-                    }
+                    if (owner_now) lit = static_cast<float>(my_lit);
                 }
                 lit *= l.inv_samples;  // light.rs:208
             }

@@ -484,7 +484,8 @@ struct DBound {  // 32 B per record: world-space bounding ball (r = +inf: unboun
     float c[3];  //  and cubes, the ball inscribed around the same centre (r_in = 0: none)
     float r;
     float r_in;
-    float pad[3];
+    float margin;  // object-space margin of the pyramid tests (spheres and cubes)
+    float pad[2];
 };
 struct Shaft {
     V3 p, lc, D;  // apex (the over point), light ball centre, lc - p
@@ -589,9 +590,107 @@ RT_HD bool shaft_leaves_solid(const Shaft& s, V3 c, float r_out) {
     float reach = s.lr + fmaf(r_out, 1.001f, 1e-4f);
     return dot(e, e) > reach * reach;
 }
+// The exact shape of a shaft is the pyramid from the apex to the light's parallelogram (the jittered
+// points of light.rs:211-216 all lie in it).  Seen from a sphere's or cube's OBJECT space (the map is
+// affine: pyramids stay pyramids, the shape becomes the unit sphere / the cube [-1, 1]^3) two sharper
+// answers than the ball tests give are cheap:
+//   pyramid_misses  : one of the four side planes through the apex separates the shape (grown by the
+//                     margin m) from the pyramid — no ray of the shaft can touch it;
+//   pyramid_blocked : the apex lies outside the grown shape and the four rays to the light's corners
+//                     all enter the shape SHRUNK by m at 1e-3 < t < 1 - 1e-3 (t = 1 at the corner).
+//                     Directions that hit a convex body form a convex cone, and the convex hull of the
+//                     four entry points is met by every ray of the pyramid at a parameter between the
+//                     smallest and largest of the four: every ray enters the shape before the light.
+// m (DBound.margin) covers the 1e-5 slack of the approximate comparisons in cube.rs:63-73 seen from
+// object space, and FP32 rounding of the maps: 1e-3 + 1e-4 |inverse|_F.
+struct ShaftObj {
+    V3 a, l0, U, V;  // apex; the light's corner and its two edges (corners l0, l0 + U, l0 + U + V, l0 + V)
+};
+RT_HD ShaftObj shaft_in_object_space(const float* inv, V3 apex, const DLight& l) {
+    ShaftObj s;
+    s.a = xform_point(inv, apex);
+    s.l0 = xform_point(inv, v3(l.pos[0], l.pos[1], l.pos[2]));
+    s.U = xform_vector(inv, v3(l.uvec[0], l.uvec[1], l.uvec[2]) * static_cast<float>(l.usteps));
+    s.V = xform_vector(inv, v3(l.vvec[0], l.vvec[1], l.vvec[2]) * static_cast<float>(l.vsteps));
+    return s;
+}
+// Written so that a far apex (|a| of 1e4 object units happens: a small shape, a point near the
+// horizon) costs no accuracy: the side plane through the apex and the light's edge E that starts at
+// corner p has the normal (p - a) x E and the offset n . a = (p x E) . a — no difference of nearly equal
+// vectors anywhere; the pyramid's orientation is the side of the light's plane the apex is on.
+RT_HD bool pyramid_misses(const ShaftObj& s, bool cube, float m) {
+    const V3 nl = cross(s.U, s.V);
+    const V3 e0 = s.l0 - s.a;
+    const float tr = dot(e0, nl);  // = (l0 - a) . ((l1 - a) x (l2 - a))
+    const float sg = tr >= 0.0f ? 1.0f : -1.0f;
+    const float grow = 1.0f + m;
+    bool out = false;
+    V3 p = s.l0, E = s.U;
+    for (int k = 0; k < 4; ++k) {
+        const V3 e = p - s.a;
+        const V3 n = cross(e, E);
+        const float ka = sg * dot(cross(p, E), s.a);  // inner side: sg n . (x - a) >= 0; the shape's centre is ka below it
+        const float nn = dot(n, n);
+        bool sep;
+        if (cube) sep = ka > (fabsf(n.x) + fabsf(n.y) + fabsf(n.z)) * grow;
+        else sep = (ka > 0.0f) & (ka * ka > nn * (grow * grow));
+        // an apex (nearly) on the edge's line leaves this plane to rounding: no answer from it
+        out |= sep & (nn > 1e-6f * dot(e, e) * dot(E, E));
+        p = p + E;
+        E = k == 0 ? s.V : (k == 1 ? neg(s.U) : neg(s.V));
+    }
+    // likewise an apex (nearly) in the light's plane, for the orientation
+    return out & (tr * tr > 1e-6f * dot(nl, nl) * dot(e0, e0));
+}
+// The four rays are followed from the light's corners towards the apex (x = l + s (a - l), s = 1 - t):
+// the corner's coordinates are of the shape's own size, so the quadratic / the slabs lose nothing.
+RT_HD bool pyramid_blocked(const ShaftObj& s, bool cube, float m) {
+    const float grow = 1.0f + m, core = 1.0f - m;
+    bool ok = core > 0.5f;
+    if (cube) ok &= fmaxf(fabsf(s.a.x), fmaxf(fabsf(s.a.y), fabsf(s.a.z))) > grow;
+    else ok &= dot(s.a, s.a) > grow * grow;
+    V3 l = s.l0;
+    for (int k = 0; k < 4; ++k) {
+        const V3 w = s.a - l;
+        float s_in, s_out;  // where the reversed ray enters and leaves the shrunk shape
+        bool hit;
+        if (cube) {
+            const V3 iw = v3(rcp_f(w.x), rcp_f(w.y), rcp_f(w.z));
+            const float x0 = (-core - l.x) * iw.x, x1 = (core - l.x) * iw.x;
+            const float y0 = (-core - l.y) * iw.y, y1 = (core - l.y) * iw.y;
+            const float z0 = (-core - l.z) * iw.z, z1 = (core - l.z) * iw.z;
+            s_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            s_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            hit = s_in < s_out;  // NaN (0 * inf) compares false
+        } else {
+            const float A = dot(w, w), B = dot(l, w), C = dot(l, l) - core * core;
+            const float disc = fmaf(B, B, -(A * C));
+            hit = (disc > 0.0f) & (A > 0.0f);
+            const float root = sqrt_f(fmaxf(disc, 0.0f)), ia = rcp_f(A);
+            s_in = (-B - root) * ia, s_out = (-B + root) * ia;
+        }
+        // the light's corner outside the shape (s_in > 0), the shape entered by the forward ray at
+        // t = 1 - s_out in (1e-3, 1 - 1e-3)
+        ok &= hit & (s_in > 1e-3f) & (s_out < 1.0f - 1e-3f);
+        l = l + (k == 0 ? s.U : (k == 1 ? s.V : neg(s.U)));
+    }
+    return ok;
+}
 // Every ray of the shaft leaves the tangent plane at the apex on the side of the normal n: a ray
 // that starts (1e-5 outside) on a CONVEX primitive with outward normal n cannot meet it again.
-RT_HD bool shaft_leaves_surface(const Shaft& s, V3 n) { return dot(s.D, n) - s.lr > 1e-3f * (s.dlen + s.lr); }
+// (the light's lowest and highest points over that plane are corners of the parallelogram.)  Returns
+// +1 for that; -1 when the WHOLE light lies below the tangent plane: then every cell fails the gate of
+// material.rs:145, both Phong sums are exactly zero and no shadow ray of the pair can change the pixel;
+// 0 when the plane cuts the light.
+RT_HD int shaft_side_of_surface(const Shaft& s, V3 n, const DLight& l) {
+    const float base = dot(v3(l.pos[0], l.pos[1], l.pos[2]) - s.p, n);
+    const float un = dot(v3(l.uvec[0], l.uvec[1], l.uvec[2]), n) * static_cast<float>(l.usteps);
+    const float vn = dot(v3(l.vvec[0], l.vvec[1], l.vvec[2]), n) * static_cast<float>(l.vsteps);
+    const float room = 1e-3f * (s.dlen + s.lr);
+    if (base + fminf(un, 0.0f) + fminf(vn, 0.0f) > room) return 1;
+    if (base + fmaxf(un, 0.0f) + fmaxf(vn, 0.0f) < -room) return -1;
+    return 0;
+}
 
 // intersection.rs:71-103 without the sorted list.  The reference walks the sorted intersections up
 // to the hit, toggling each object in a container list; n1 is the material of the list's last entry

@@ -196,6 +196,9 @@ inline DBound prim_world_ball(uint32_t type, const float* inv, const float* para
         for (int i = 0; i < 3; ++i) worst = std::max(worst, type == RT_PRIM_CUBE ? g[i][i] : std::fabs(g[i][0]) + std::fabs(g[i][1]) + std::fabs(g[i][2]));
         const double rin = (worst > 0.0 ? 1.0 / std::sqrt(worst) : 0.0) * (1.0 - 1e-4);
         if (std::isfinite(rin) && rin > 0.0 && rin < r) out.r_in = static_cast<float>(rin);
+        // margin of the object-space pyramid tests (rt_math.h ShaftObj); 0 = do not use them
+        const double margin = 1e-3 + 1e-4 * std::sqrt(g[0][0] + g[1][1] + g[2][2]);
+        if (std::isfinite(margin) && margin < 0.25) out.margin = static_cast<float>(margin);
     }
     return out;
 }

@@ -114,7 +114,7 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
 // occludes one of them although it was ruled out is a violation (there must be none).
 std::atomic<bool> g_audit{false};
 std::atomic<uint64_t> g_audit_pairs{0}, g_audit_ruled_out{0}, g_audit_open{0}, g_audit_violations{0}, g_audit_umbra{0},
-    g_audit_umbra_violations{0}, g_audit_front{0}, g_audit_dull{0}, g_audit_phong_violations{0};
+    g_audit_umbra_violations{0}, g_audit_front{0}, g_audit_dull{0}, g_audit_phong_violations{0}, g_audit_behind{0};
 
 void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key, uint32_t node, V3 over, const HitInfo& h,
                  uint32_t self, float shininess) {
@@ -140,7 +140,19 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
                     if (pb.no_spec && spec != 0.0f) g_audit_phong_violations += 1;
                 }
     }
-    const bool self_clear = !h.inside && shaft_leaves_surface(sh, h.n);
+    const int side = shaft_side_of_surface(sh, h.n, l);
+    const bool self_clear = !h.inside && side > 0;
+    if (side < 0) {  // declared "whole light behind the surface": every cell's Phong terms must be gated off
+        const PhongPoint pp = phong_point(over, h.n, h.eye, shininess);
+        g_audit_behind += 1;
+        for (uint32_t cv = 0; cv < l.vsteps; ++cv)
+            for (uint32_t cu = 0; cu < l.usteps; ++cu) {
+                float ldn, spec;
+                phong_cell(pp, point_on_light(l, cu, cv, 0.5f, 0.5f), ldn, spec);
+                if (ldn != 0.0f || spec != 0.0f) g_audit_phong_violations += 1;
+            }
+        return;  // the kernel asks nothing else about this pair
+    }
     uint32_t prims = 0, ruled_out = 0;
     bool umbra = false;  // some primitive occludes EVERY ray of the shaft (rt_math.h shaft_blocked_by_*)
     for (uint32_t i = 0; i < n;) {  // the walk of rt_kernel.h, one "lane"
@@ -159,13 +171,19 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
                 umbra |= shaft_leaves_solid(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
         }
         else mb = shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r) && (r.type != PRIM_CUBE || shaft_meets_cube(sh, r.inv));
-        may[i] = mb;
-        if (mb && i != self && (!s.ps.has_gates || s.ps.gate[i] == kNoGate)) {
+        const bool ungated = !s.ps.has_gates || s.ps.gate[i] == kNoGate;
+        if (mb && i != self && ungated) {
             if (r.type == PRIM_PLANE)
                 umbra |= shaft_blocked_by_plane(sh, r.inv, fmaf(r.inv[4], over.x, fmaf(r.inv[5], over.y, fmaf(r.inv[6], over.z, r.inv[7]))));
             else if (b.r_in > 0.0f)
                 umbra |= shaft_blocked_by_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r_in, b.r);
         }
+        if (mb && i != self && r.type != PRIM_PLANE && b.margin > 0.0f) {  // the pyramid tests (rt_math.h ShaftObj)
+            const ShaftObj so = shaft_in_object_space(r.inv, over, l);
+            if (pyramid_misses(so, r.type == PRIM_CUBE, b.margin)) mb = false;
+            else if (ungated) umbra |= pyramid_blocked(so, r.type == PRIM_CUBE, b.margin);
+        }
+        may[i] = mb;
         ++i;
     }
     if (umbra) {  // then every ray to every cell (jittered point and corners) must be occluded
@@ -373,16 +391,17 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
 // audited, out[1] = primitives ruled out in total, out[2] = pairs with every primitive ruled out,
 // out[3] = violations (both kinds), out[4] = pairs declared fully occluded, out[5] = rays of those found unoccluded,
 // out[6] = pairs whose cells are all declared far and in front, out[7] = pairs declared free of highlights,
-// out[8] = cells contradicting either declaration.
+// out[8] = cells contradicting either declaration (or the one of out[9]), out[9] = pairs whose light is
+// declared wholly behind the surface.
 extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
                                    float* rgb_out, uint64_t* out, char* err_out, int err_cap) {
     g_audit_pairs = 0, g_audit_ruled_out = 0, g_audit_open = 0, g_audit_violations = 0, g_audit_umbra = 0, g_audit_umbra_violations = 0;
-    g_audit_front = 0, g_audit_dull = 0, g_audit_phong_violations = 0;
+    g_audit_front = 0, g_audit_dull = 0, g_audit_phong_violations = 0, g_audit_behind = 0;
     g_audit = true;
     const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
     g_audit = false;
     out[0] = g_audit_pairs, out[1] = g_audit_ruled_out, out[2] = g_audit_open, out[3] = g_audit_violations;
     out[4] = g_audit_umbra, out[5] = g_audit_umbra_violations;
-    out[6] = g_audit_front, out[7] = g_audit_dull, out[8] = g_audit_phong_violations;
+    out[6] = g_audit_front, out[7] = g_audit_dull, out[8] = g_audit_phong_violations, out[9] = g_audit_behind;
     return rc;
 }

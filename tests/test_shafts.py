@@ -28,13 +28,14 @@ def audit(scene_desc_ptr, camera_desc_ptr, seed=0, depth=3):
     opt = RtOptions()
     opt.jitter_mode, opt.seed, opt.max_depth = 1, seed, depth
     img = np.zeros((cam.vsize, cam.hsize, 3), dtype=np.float32)
-    out = np.zeros(9, dtype=np.uint64)
+    out = np.zeros(10, dtype=np.uint64)
     err = C.create_string_buffer(256)
     rc = L.hostsim_shaft_audit(C.cast(scene_desc_ptr, C.c_void_p), C.cast(camera_desc_ptr, C.c_void_p),
                                C.cast(C.byref(opt), C.c_void_p), img.ctypes.data, out.ctypes.data, err, 256)
     assert rc == 0, err.value.decode()
     return dict(pairs=int(out[0]), ruled_out=int(out[1]), open=int(out[2]), violations=int(out[3]), umbra=int(out[4]),
-                umbra_violations=int(out[5]), front=int(out[6]), dull=int(out[7]), phong_violations=int(out[8]))
+                umbra_violations=int(out[5]), front=int(out[6]), dull=int(out[7]), phong_violations=int(out[8]),
+                behind=int(out[9]))
 
 
 @pytest.mark.parametrize("name", ["checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
@@ -46,7 +47,7 @@ def test_no_occluder_is_ruled_out_in_the_example_scenes(name):
     # the test has teeth only if the shafts do rule things out
     assert r["ruled_out"] > 0 and r["open"] > 0, r
     # the bounds that drop the per-cell gates of the Phong sums: used, and never contradicted by a cell
-    assert r["front"] > 0 and r["dull"] > 0 and r["phong_violations"] == 0, r
+    assert r["front"] > 0 and r["dull"] > 0 and r["behind"] > 0 and r["phong_violations"] == 0, r
 
 
 @pytest.mark.parametrize("name", ["striped_sphere_multiple_lights", "glass_sphere_checkered_floor_aerial_view",
@@ -147,7 +148,7 @@ def random_scene(rng, n_objects, keep):
 @pytest.mark.parametrize("n_objects", [1, 3, 6, 12, 30])  # <= 8 primitives: flat stream; more: hierarchy
 def test_no_occluder_is_ruled_out_in_random_scenes(n_objects):
     cam = ExampleScene("striped_sphere_multiple_lights", 40, 24)  # eye (0, 3, 5) looking at (0, 1, 0)
-    tot = dict(pairs=0, ruled_out=0, open=0, violations=0, umbra=0, umbra_violations=0, front=0, dull=0, phong_violations=0)
+    tot = dict(pairs=0, ruled_out=0, open=0, violations=0, umbra=0, umbra_violations=0, front=0, dull=0, phong_violations=0, behind=0)
     for seed in range(16):
         rng = np.random.default_rng(1000 * n_objects + seed)
         keep = []
@@ -157,7 +158,7 @@ def test_no_occluder_is_ruled_out_in_random_scenes(n_objects):
             tot[k] += r[k]
     assert tot["pairs"] > 1000 and tot["violations"] == 0, tot
     assert tot["ruled_out"] > 0 and tot["umbra"] > 0 and tot["umbra_violations"] == 0, tot
-    assert tot["front"] > 0 and tot["dull"] > 0 and tot["phong_violations"] == 0, tot
+    assert tot["front"] > 0 and tot["dull"] > 0 and tot["behind"] > 0 and tot["phong_violations"] == 0, tot
 
 
 def many_planes_scene(rng, keep, n_planes=70):
