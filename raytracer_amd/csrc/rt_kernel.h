@@ -269,8 +269,12 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t wave, u
     return x < P.cam.hsize && yl < P.out_rows && gy < P.cam.vsize;
 }
 
+// Waves per SIMD by instantiation, as measured (profiles/r01_occupancy_by_variant_v39.txt): the
+// area-light variants of flat streams and of streams with cylinders/triangles need about 140-170
+// VGPRs and run faster at 3 waves without spills than at 4 with 60-80 spilled registers; the rest fit 128.
+constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) { return AREA && (!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS; }
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
-__global__ __launch_bounds__(256, RT_MIN_BLOCKS) void render_kernel(const KParams P) {
+__global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave >= P.n_tiles) return;
