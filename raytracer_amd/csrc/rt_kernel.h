@@ -17,19 +17,23 @@
 //              light, three parts:
 //                shafts       each lane tests the shaft from ITS shading point to the light
 //                             (rt_math.h "Shafts") against the stream: records that provably stay
-//                             outside cannot occlude whatever the jitter.  No possible blocker: the
-//                             point is fully lit without casting; otherwise the survivors form a
-//                             record mask (streams of <= 64 records) for the passes below.
-//                visibility   wave-cooperative: the wave's shading points are taken one (>= 64
-//                             cells) or several (16 cells: four) at a time, ONE LIGHT CELL PER LANE;
-//                             the shadow rays of a pass leave the same point (coherent, they exit
-//                             together), the count is a ballot + popcount.  Lanes whose own pixel
-//                             has nothing to shade still work for their neighbours, which keeps the
-//                             wave full on deep glass paths (>= 98 % of all rays are such rays).
+//                             outside cannot occlude whatever the jitter; a primitive that provably
+//                             blocks the whole shaft settles the opposite answer.  A second walk
+//                             over the records still flagged looks at the exact pyramid point ->
+//                             parallelogram in the object space of each sphere or cube.  No possible
+//                             blocker: fully lit without casting; blocked: lit = 0 without casting;
+//                             whole light behind the surface: nothing to find out; otherwise the
+//                             survivors form a record mask (streams of <= 64 records) for the passes.
 //                Phong sums   over the cell CENTRES (material.rs:133-161), independent of the
-//                             shadow rays: lane-local loop over the cells when most lanes have a
-//                             hit (no cross-lane traffic at all), folded into the cooperative
-//                             passes with a butterfly reduction when only a few have.
+//                             shadow rays: every lane for its own point, the cell quantities as
+//                             forms in the cell indices (rt_math.h PhongGrid); the per-cell gates
+//                             are dropped when bounds over the light show they cannot fire.
+//                visibility   what is left (true penumbra, mostly) is wave-cooperative: the wave's
+//                             shading points are taken one (>= 64 cells) or several (16 cells: four)
+//                             at a time, ONE LIGHT CELL PER LANE; the shadow rays of a pass leave the
+//                             same point (coherent, they exit together), the count is a ballot +
+//                             popcount.  Lanes whose own pixel has nothing to shade still work for
+//                             their neighbours, which keeps the wave full on deep glass paths.
 //   children   reflection / refraction rays (world.rs:94-133); one continues in the lane, the other
 //              goes to the lane's stack (private memory, touched once per two-child node).
 //
