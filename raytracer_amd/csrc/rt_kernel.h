@@ -264,8 +264,22 @@ __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - stati
 // EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
 // hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
 // The pixel of a lane: column x, row yl of this call's packed output, global row gy; false = outside.
-__device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t wave, uint32_t lane, uint32_t& x, uint32_t& yl, uint32_t& gy) {
-    const uint32_t tile_y = wave / P.tiles_x, tile_x = wave - tile_y * P.tiles_x;
+__device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, uint32_t wave, uint32_t lane, uint32_t& x, uint32_t& yl, uint32_t& gy) {
+    const uint32_t slot_y = wave / P.tiles_x, tile_x = wave - slot_y * P.tiles_x;
+    // Tile rows are handed out from the middle of the image outwards (c, c-1, c+1, c-2, ...): the
+    // expensive tiles (penumbrae, glass) are rarely at the top or bottom edge, and a tile whose 64
+    // points all sit in two penumbrae runs ~0.1 ms on its own — started last it IS the frame time.
+    uint32_t tile_y = slot_y;
+    const uint32_t tiles_y = P.n_tiles / P.tiles_x;
+    if (order == 1u) {
+        const uint32_t c = (tiles_y - (tiles_y & 1u)) >> 1;
+        tile_y = (slot_y & 1u) ? c - ((slot_y + 1u) >> 1) : c + (slot_y >> 1);
+    } else if (order == 2u) {  // bottom row first
+        tile_y = tiles_y - 1u - slot_y;
+    } else if (order == 3u) {  // from the middle down, then from the middle up
+        const uint32_t c = tiles_y >> 1;
+        tile_y = slot_y < tiles_y - c ? c + slot_y : tiles_y - 1u - slot_y;
+    }
     x = tile_x * 8u + (lane & 7u);
     yl = tile_y * 8u + (lane >> 3);
     const uint32_t band = yl / P.tile_rows;
@@ -279,13 +293,18 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t wave, u
 constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) { return AREA && (!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS; }
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
 __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
+#ifdef RT_ORDER
+    constexpr uint32_t kOrder = RT_ORDER;  // experiments
+#else
+    constexpr uint32_t kOrder = AREA ? 1u : 0u;
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave >= P.n_tiles) return;
     const KScene& sc = P.sc;
 
     uint32_t x, yl, gy;
-    const bool valid = pixel_of_lane(P, wave, lane, x, yl, gy);
+    const bool valid = pixel_of_lane(P, kOrder, wave, lane, x, yl, gy);
 
     const uint32_t pixel_key = jitter_pixel_key(P.seed, gy * P.cam.hsize + x);
     const float nlights = static_cast<float>(sc.n_lights);
@@ -734,7 +753,7 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
         uint32_t lane_again = threadIdx.x & 63u;
         asm volatile("" : "+v"(lane_again));
         uint32_t ox, oyl, ogy;
-        if (pixel_of_lane(P, wave, lane_again, ox, oyl, ogy)) {
+        if (pixel_of_lane(P, kOrder, wave, lane_again, ox, oyl, ogy)) {
             float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
