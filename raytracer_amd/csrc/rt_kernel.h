@@ -52,6 +52,9 @@
 #ifndef RT_MIN_BLOCKS
 #define RT_MIN_BLOCKS 4  // 256-thread blocks per CU = waves per SIMD (occupancy sweeps override it)
 #endif
+#ifndef RT_LOCAL_CAST_MIN
+#define RT_LOCAL_CAST_MIN 16  // points of a tile that need shadow rays: from here on each lane casts its own
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // request record i+1 while record i is processed (costs 16 SGPR copies per record)
 #endif
@@ -608,6 +611,66 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                 }
 
                 if (RT_EXP & 1024) need = 0;
+                // A tile with many such points (it lies in a penumbra): every lane casts its OWN
+                // point's rays, cell after cell, record after record of the lanes' masks.  An
+                // iteration has no cross-lane traffic and no memory access — the record under test
+                // stays in SGPRs for all cells — so the 64 + 16 dependent passes of a tile inside two
+                // penumbrae (~1 us each: LDS broadcast, jitter, scalar record load, test, ballot)
+                // become 80 short iterations.  That chain of ONE wave was a fixed ~0.08 ms of a frame
+                // however small the frame (profiles/r01_c2_size_sweep_v40.txt).  Few points: the
+                // cooperative passes below cost less, they only run for the points that need them.
+                if (by_mask && cells <= 64u && static_cast<uint32_t>(__popcll(need)) >= RT_LOCAL_CAST_MIN && !(RT_EXP & 8192)) {
+                    const bool mine = ((need >> lane) & 1ull) != 0ull;
+                    mask_t rem = mine ? blockers : mask_t(0);
+                    if (!wave_any(((rem >> kTopBit) & mask_t(1)) != 0)) {  // (the shared top bit: cooperative passes)
+                        Ray sr;
+                        sr.o = h_over(), sr.q = h_q(), sr.dq = h_dq(), sr.self = h_prim();
+                        sr.d = v3(0.0f, 0.0f, 0.0f);
+                        const uint32_t key = __float_as_uint(park[34 * 256]);
+                        unsigned long long occ_bits = 0ull;  // this lane's cells found occluded so far
+                        bool first = true;
+                        for (;;) {
+                            const unsigned long long todo = wave_ballot(rem != 0);
+                            if (!todo) break;
+                            const int lead = __ffsll(static_cast<long long>(todo)) - 1;  // some lane with work: its lowest record
+                            uint32_t i;
+                            if (TREE) {
+                                const uint32_t lo = rl_u(static_cast<uint32_t>(rem), lead);
+                                const uint32_t hi = rl_u(static_cast<uint32_t>(static_cast<unsigned long long>(rem) >> 32), lead);
+                                i = lo ? static_cast<uint32_t>(__builtin_ctz(lo)) : 32u + static_cast<uint32_t>(__builtin_ctz(hi));
+                            } else {
+                                i = static_cast<uint32_t>(__builtin_ctz(rl_u(static_cast<uint32_t>(rem), lead)));
+                            }
+                            const bool has = ((rem >> i) & mask_t(1)) != 0;
+                            rem &= ~(mask_t(1) << i);
+                            const DPrim rec = sc.recs[i];
+                            const bool on_self = i == sr.self;
+                            uint32_t cu = 0, cv = 0;
+                            for (uint32_t cell = 0; cell < cells; ++cell) {
+                                float ju = 0.5f, jv = 0.5f;
+                                if (P.jitter_mode == RT_JITTER_COUNTER) counter_jitter(key, node, li, cell, ju, jv);
+                                const V3 tl = point_on_light(l, cu, cv, ju, jv) - sr.o;
+                                const float dist2 = dot(tl, tl);
+                                const float inv_dist = rsq_f(dist2);
+                                const float dist = dist2 * inv_dist;
+                                const bool ray = dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
+                                sr.d = tl * inv_dist;
+                                bool hit = false;
+                                if (has && ray && !((occ_bits >> cell) & 1ull)) {
+                                    if (on_self) intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+                                    else hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
+                                    if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
+                                }
+                                if (hit) occ_bits |= 1ull << cell;
+                                if (STATS && first && mine && ray) c_shadow++;
+                                if (++cu == l.usteps) cu = 0u, ++cv;
+                            }
+                            first = false;
+                        }
+                        if (mine) lit = static_cast<float>(cells - static_cast<uint32_t>(__popcll(occ_bits)));
+                        need = 0ull;
+                    }
+                }
                 while (need) {
                     // the shading points ("owners") of this pass: one per slot of g lanes
                     int owner = 0;
