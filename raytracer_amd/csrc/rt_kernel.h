@@ -28,7 +28,10 @@
 //                             shadow rays: every lane for its own point, the cell quantities as
 //                             forms in the cell indices (rt_math.h PhongGrid); the per-cell gates
 //                             are dropped when bounds over the light show they cannot fire.
-//                visibility   what is left (true penumbra, mostly) is wave-cooperative: the wave's
+//                visibility   what is left (true penumbra, mostly).  A tile with many such points:
+//                             every lane casts its own point's rays, cell after cell, the record
+//                             under test in SGPRs (no cross-lane traffic, no memory access per ray).
+//                             A tile with few of them is wave-cooperative: the wave's
 //                             shading points are taken one (>= 64 cells) or several (16 cells: four)
 //                             at a time, ONE LIGHT CELL PER LANE; the shadow rays of a pass leave the
 //                             same point (coherent, they exit together), the count is a ballot +
