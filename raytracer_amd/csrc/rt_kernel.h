@@ -58,6 +58,9 @@
 #ifndef RT_LOCAL_CAST_MIN
 #define RT_LOCAL_CAST_MIN 16  // points of a tile that need shadow rays: from here on each lane casts its own
 #endif
+#ifndef RT_SHARED_PHONG_MAX
+#define RT_SHARED_PHONG_MAX 8  // up to this many shading points in a wave: the lanes share out their Phong sums
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // request record i+1 while record i is processed (costs 16 SGPR copies per record)
 #endif
@@ -586,7 +589,48 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
 
                 // Phong sums over the cell centres, every lane for its own point, cells in the
                 // reference's order (material.rs:133-136).
-                if (wave_ballot(shades) & ~behind_mask) {  // (a tile of faces turned away from the light has nothing to sum)
+                const unsigned long long summing = wave_ballot(shades) & ~behind_mask;
+                const uint32_t n_summing = static_cast<uint32_t>(__popcll(summing));
+                if (AREA && n_summing != 0u && n_summing <= RT_SHARED_PHONG_MAX && cells >= 16u && !(RT_EXP & 16384)) {
+                    // Few points in the wave (deep glass paths): the lanes share them out.  Each point
+                    // gets 64 / 2^ceil(log2 n) lanes, each of which sums a run of its cells from the
+                    // point's parked data (an LDS broadcast); a butterfly adds the runs up.
+                    uint32_t plog = 0;
+                    while ((1u << plog) < n_summing) ++plog;
+                    const uint32_t glog2 = 6u - plog, gl = 1u << glog2;  // lanes per point
+                    const uint32_t rank = lane >> glog2, part = lane & (gl - 1u);
+                    int whose = -1;
+                    {
+                        unsigned long long a = summing;
+                        for (uint32_t k = 0; a; ++k) {
+                            const int o = __ffsll(static_cast<long long>(a)) - 1;
+                            a &= a - 1ull;
+                            if (rank == k) whose = o;
+                        }
+                    }
+                    const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(whose < 0 ? 0 : whose);
+                    auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
+                    const PhongPoint pp = phong_point(od3(24), od3(17), od3(20), op[23 * 256]);
+                    const uint32_t per = (cells + gl - 1u) >> glog2;
+                    uint32_t c = part * per;
+                    uint32_t cv = c / l.usteps, cu = c - cv * l.usteps;
+                    float part_d = 0.0f, part_s = 0.0f;
+                    for (uint32_t j = 0; j < per; ++j, ++c) {
+                        if (whose >= 0 && c < cells) {
+                            float ldn, spec;
+                            phong_cell(pp, point_on_light(l, cu, cv, 0.5f, 0.5f), ldn, spec);
+                            part_d += ldn, part_s += spec;
+                        }
+                        if (++cu == l.usteps) cu = 0u, ++cv;
+                    }
+                    for (uint32_t st = 1; st < gl; st <<= 1) {
+                        part_d += __shfl_xor(part_d, static_cast<int>(st), 64);
+                        part_s += __shfl_xor(part_s, static_cast<int>(st), 64);
+                    }
+                    const uint32_t my_rank = static_cast<uint32_t>(__popcll(summing & ((1ull << lane) - 1ull)));
+                    const float got_d = shfl_f(part_d, static_cast<int>(my_rank << glog2)), got_s = shfl_f(part_s, static_cast<int>(my_rank << glog2));
+                    if ((summing >> lane) & 1ull) sum_d = got_d, sum_s = got_s;
+                } else if (summing) {  // (a tile of faces turned away from the light has nothing to sum)
                     PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
                     if (!shades) pp.gate = INFINITY;  // lanes without a shading point run along and are zeroed below
                     const PhongGrid pg = phong_grid(pp, l);
