@@ -51,6 +51,10 @@
 
 #ifndef RT_EXP
 #define RT_EXP 0  // timing experiments only (scripts/exp_variants.sh): knock out one phase of the shading pass
+// bits: 4 no occlusion test in the cooperative passes | 16 spheres never occlude | 32 no shaft tests |
+// 64 no container pass | 128 no point-light shadow rays | 256 per-lane traversal | 512 Phong sums over one
+// cell | 1024 no shadow casting for area lights | 2048 no pyramid walk | 8192 no lane-local casting |
+// 16384 no shared Phong sums.  Every one of them renders a WRONG image except 2048, 8192 and 16384.
 #endif
 #ifndef RT_MIN_BLOCKS
 #define RT_MIN_BLOCKS 4  // 256-thread blocks per CU = waves per SIMD (occupancy sweeps override it)
