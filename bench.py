@@ -14,6 +14,11 @@ is assembled in rank 0's HBM inside the timed region ("strong" scaling):
               (rt_frame_open, peer access over xGMI) and their kernels store their rows straight into
               it (RT_FLAG_GLOBAL_ROWS) — no collective and no staging copy on the data path; ranks
               only meet at the barriers that bracket the timed region;
+  * "copy2d": the same shared frame, but every rank renders into its own HBM and then moves its bands
+              with ONE strided device-to-device copy (hipMemcpy2DAsync, bands are 8 rows apart by N)
+              — a bulk transfer instead of the kernel's 12-byte stores over the fabric.  Which of the
+              two is faster depends on the links; a few untimed frames of each decide (both leave the
+              same frame, and it is verified bit for bit either way);
   * "gather": if the shared frame cannot be set up on every rank, the packed bands go through an RCCL
               gather to rank 0 and are re-interleaved there (the round-1 path, kept as plumbing
               fallback — both paths run the same kernels).
@@ -189,12 +194,40 @@ def main():
         perm = torch.from_numpy(partition.gather_permutation(height, world)).to(dev)
         final = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
 
+    hip = None
+    if mode == "p2p":
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                             C.c_void_p]
+            hip.hipMemcpy2DAsync.restype = C.c_int
+        except (OSError, AttributeError):
+            hip = None
+    my_rows = int(scene.output_rows(ex.camera_desc, opt))
+    band_bytes = BAND_ROWS * width * 12
+
+    def move_bands(stream):
+        """This rank's packed bands -> their rows of the shared frame: one strided copy (+ a last partial band)."""
+        full, tail = divmod(my_rows, BAND_ROWS)
+        dst0 = shared.ptr.value + rank * band_bytes
+        if full:
+            rc = hip.hipMemcpy2DAsync(dst0, world * band_bytes, local.data_ptr(), band_bytes, band_bytes, full, 4, stream)
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy2DAsync failed ({rc})")
+        if tail:
+            rc = hip.hipMemcpy2DAsync(dst0 + full * world * band_bytes, tail * width * 12, local.data_ptr() + full * band_bytes,
+                                      tail * width * 12, tail * width * 12, 1, 4, stream)
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy2DAsync failed ({rc})")
+
     def frame():
         stream = torch.cuda.current_stream().cuda_stream
         if mode == "p2p":
             scene.render_device(ex.camera_desc, shared.ptr.value, opt_frame, stream)
             return
         scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
+        if mode == "copy2d":
+            move_bands(stream)
         if mode == "gather":
             dist.gather(local, gathered, dst=0)
             if rank == 0:
@@ -219,6 +252,31 @@ def main():
                             st.light_cells, st.pattern_lookups, st.container_passes)))
     total_rays = total["primary_rays"] + total["reflection_rays"] + total["refraction_rays"] + total["shadow_rays"]
 
+    # direct stores or one strided copy per rank?  A few untimed frames of each; every rank takes the
+    # same decision because it is taken on the all-reduced times.
+    calibration = None
+    if mode == "p2p" and hip is not None:
+        took = {}
+        for m in ("p2p", "copy2d"):
+            mode = m
+            ok = 1
+            try:
+                frame()
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    frame()
+                sync_all()
+                took[m] = time.perf_counter() - t0
+            except RuntimeError as e:
+                print(f"bench.py: rank {rank}: {m} not usable ({e})", file=sys.stderr)
+                ok, took[m] = 0, float("inf")
+            flag = torch.tensor([took[m] if ok else 1e30], dtype=torch.float64, device=ctl)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            took[m] = float(flag.item())
+        mode = "copy2d" if took["copy2d"] < took["p2p"] else "p2p"
+        calibration = {k: (v / 5 * 1e3 if v < 1e29 else None) for k, v in took.items()}
+
     for _ in range(args.warmup):
         frame()
     sync_all()
@@ -232,6 +290,8 @@ def main():
         else:
             scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
         ev[k][1].record()
+        if mode == "copy2d":
+            move_bands(stream)
         if mode == "gather":
             dist.gather(local, gathered, dst=0)
             if rank == 0:
@@ -248,7 +308,7 @@ def main():
     verified = None
     if world > 1 and rank == 0:
         whole, _ = scene.render(ex.camera_desc, base)
-        got = shared.download() if mode == "p2p" else final.cpu().numpy()
+        got = shared.download() if mode in ("p2p", "copy2d") else final.cpu().numpy()
         verified = bool(np.array_equal(whole, got))
 
     if rank == 0:
@@ -276,8 +336,12 @@ def main():
                 "partition": "whole frame on one GPU" if world == 1 else (
                     f"interleaved {BAND_ROWS}-row bands over {world} GPUs, every rank's kernel stores its rows straight "
                     f"into ONE frame in rank 0's HBM (peer access over xGMI, no collective)" if mode == "p2p" else
+                    f"interleaved {BAND_ROWS}-row bands over {world} GPUs, every rank moves its bands with one strided "
+                    f"device-to-device copy into ONE frame in rank 0's HBM (peer access over xGMI, no collective)"
+                    if mode == "copy2d" else
                     f"interleaved {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"),
-                "assembly": mode, "assembled_frame_equals_single_gpu_frame": verified,
+                "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
+                "assembled_frame_equals_single_gpu_frame": verified,
                 "rays_per_frame": total_rays, "rays_by_kind": total,
             },
             "frame_ms": ms_per_step,
