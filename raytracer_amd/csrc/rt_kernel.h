@@ -300,10 +300,17 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
     return x < P.cam.hsize && yl < P.out_rows && gy < P.cam.vsize;
 }
 
-// Waves per SIMD by instantiation, as measured (profiles/r01_occupancy_by_variant_v39.txt): the
-// area-light variants of flat streams and of streams with cylinders/triangles need about 140-170
-// VGPRs and run faster at 3 waves without spills than at 4 with 60-80 spilled registers; the rest fit 128.
-constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) { return AREA && (!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS; }
+// Waves per SIMD by instantiation, as measured (profiles/r01_occupancy_by_variant_v39.txt, _v43.txt):
+// the kernels without area-light code take 5 (96 VGPRs, 12-31 spilled registers; C4 11.9 -> 10.6 ms,
+// 6 waves are slower again); the area-light variants of flat streams and of streams with
+// cylinders/triangles need about 140-170 VGPRs and run faster at 3 waves without spills than at 4 with
+// 60-80 spilled registers; the area-light variant of plain hierarchies stays at 4.
+#ifndef RT_MIN_BLOCKS_PLAIN
+#define RT_MIN_BLOCKS_PLAIN 5
+#endif
+constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) {
+    return !AREA ? RT_MIN_BLOCKS_PLAIN : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
+}
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
 __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
 #ifdef RT_ORDER
