@@ -111,7 +111,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     const uint32_t tiles_y = (rp.out_rows + 7u) / 8u;
     P.n_tiles = P.tiles_x * tiles_y;
     if (P.n_tiles == 0) return RT_OK;
-    const uint32_t blocks = (P.n_tiles + 3u) / 4u;  // 4 waves (tiles) per 256-thread block
+    const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
+    const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
     // sixteen instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code
     if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
@@ -124,7 +125,7 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
         render_kernel<true, false, true, false>,   render_kernel<true, false, true, true>,
         render_kernel<true, true, false, false>,   render_kernel<true, true, false, true>,
         render_kernel<true, true, true, false>,    render_kernel<true, true, true, true>};
-    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -56,8 +56,15 @@
 // cell | 1024 no shadow casting for area lights | 2048 no pyramid walk | 8192 no lane-local casting |
 // 16384 no shared Phong sums.  Every one of them renders a WRONG image except 2048, 8192 and 16384.
 #endif
+#ifndef RT_BLOCK_THREADS
+// One tile (one wave) per workgroup: tiles differ in cost by an order of magnitude, and with four to a
+// workgroup a new workgroup had to wait for a free wave slot on EVERY SIMD of a CU and for the LDS of a
+// whole finished workgroup (profiles/r01_block_size_v45.txt: C4 10.8 -> 9.0 ms, cover_image_area
+// 2.01 -> 1.76 ms with 64 threads instead of 256).
+#define RT_BLOCK_THREADS 64
+#endif
 #ifndef RT_MIN_BLOCKS
-#define RT_MIN_BLOCKS 4  // 256-thread blocks per CU = waves per SIMD (occupancy sweeps override it)
+#define RT_MIN_BLOCKS 4  // waves per SIMD (__launch_bounds__' second argument in HIP; occupancy sweeps override it)
 #endif
 #ifndef RT_LOCAL_CAST_MIN
 #define RT_LOCAL_CAST_MIN 16  // points of a tile that need shadow rays: from here on each lane casts its own
@@ -70,6 +77,8 @@
 #endif
 
 namespace rtk {
+
+constexpr uint32_t kBlockThreads = RT_BLOCK_THREADS;
 
 struct KScene {
     const DPrim* recs;      // the traversal stream (rt_math.h, rt_pack.h)
@@ -312,7 +321,7 @@ constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) {
     return !AREA ? RT_MIN_BLOCKS_PLAIN : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
 }
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
-__global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
+__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
 #ifdef RT_ORDER
     constexpr uint32_t kOrder = RT_ORDER;  // experiments
 #else
@@ -345,9 +354,9 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
-    __shared__ float s_park[(AREA ? 35 : 24) * 256];
+    __shared__ float s_park[(AREA ? 35 : 24) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
-    if (AREA) park[34 * 256] = __uint_as_float(pixel_key);
+    if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
                        c_cells = 0, c_pattern = 0, c_container = 0;
@@ -428,9 +437,9 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
         }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
-        auto ld3 = [&](int k) { return v3(park[k * 256], park[(k + 1) * 256], park[(k + 2) * 256]); };
-        park[17 * 256] = nrm.x, park[18 * 256] = nrm.y, park[19 * 256] = nrm.z;
-        park[20 * 256] = -cur.d.x, park[21 * 256] = -cur.d.y, park[22 * 256] = -cur.d.z;
+        auto ld3 = [&](int k) { return v3(park[k * kBlockThreads], park[(k + 1) * kBlockThreads], park[(k + 2) * kBlockThreads]); };
+        park[17 * kBlockThreads] = nrm.x, park[18 * kBlockThreads] = nrm.y, park[19 * kBlockThreads] = nrm.z;
+        park[20 * kBlockThreads] = -cur.d.x, park[21 * kBlockThreads] = -cur.d.y, park[22 * kBlockThreads] = -cur.d.z;
 
         // ---------------------------------------------------------------- shade (world.rs:43-58)
         float m_ambient = 0.0f, m_diffuse = 0.0f, m_specular = 0.0f, m_shininess = 1.0f;
@@ -438,30 +447,30 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
             const DMaterial m = sc.mats[mi];
             m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
         }
-        park[23 * 256] = m_shininess;
+        park[23 * kBlockThreads] = m_shininess;
         // material.rs:146-159: diffuse and specular are products with these two coefficients; when both
         // are zero no light sample and no shadow ray can change the pixel (ambient only)
         const bool shades = has_hit && (m_diffuse != 0.0f || m_specular != 0.0f);
-        // What the light loops do not touch waits in LDS (slot k of this lane at park[k * 256]): the
+        // What the light loops do not touch waits in LDS (slot k of this lane at park[k * kBlockThreads]): the
         // shading loops need every register they can get at 4 waves/SIMD, and a value parked here
         // costs no memory traffic, unlike a compiler spill to scratch.
-        park[0 * 256] = w.x, park[1 * 256] = w.y, park[2 * 256] = w.z;
-        park[3 * 256] = acc.x, park[4 * 256] = acc.y, park[5 * 256] = acc.z;
-        park[6 * 256] = n1, park[7 * 256] = n2;
-        park[8 * 256] = pc.x, park[9 * 256] = pc.y, park[10 * 256] = pc.z;
-        park[11 * 256] = m_ambient, park[12 * 256] = m_diffuse, park[13 * 256] = m_specular;
-        park[14 * 256] = 0.0f, park[15 * 256] = 0.0f, park[16 * 256] = 0.0f;  // surface colour so far
+        park[0 * kBlockThreads] = w.x, park[1 * kBlockThreads] = w.y, park[2 * kBlockThreads] = w.z;
+        park[3 * kBlockThreads] = acc.x, park[4 * kBlockThreads] = acc.y, park[5 * kBlockThreads] = acc.z;
+        park[6 * kBlockThreads] = n1, park[7 * kBlockThreads] = n2;
+        park[8 * kBlockThreads] = pc.x, park[9 * kBlockThreads] = pc.y, park[10 * kBlockThreads] = pc.z;
+        park[11 * kBlockThreads] = m_ambient, park[12 * kBlockThreads] = m_diffuse, park[13 * kBlockThreads] = m_specular;
+        park[14 * kBlockThreads] = 0.0f, park[15 * kBlockThreads] = 0.0f, park[16 * kBlockThreads] = 0.0f;  // surface colour so far
         if (AREA) {
-            park[24 * 256] = over.x, park[25 * 256] = over.y, park[26 * 256] = over.z;
-            park[27 * 256] = hq.x, park[28 * 256] = hq.y, park[29 * 256] = hq.z;
-            park[30 * 256] = hdq.x, park[31 * 256] = hdq.y, park[32 * 256] = hdq.z;
-            park[33 * 256] = __uint_as_float(hit_prim);
+            park[24 * kBlockThreads] = over.x, park[25 * kBlockThreads] = over.y, park[26 * kBlockThreads] = over.z;
+            park[27 * kBlockThreads] = hq.x, park[28 * kBlockThreads] = hq.y, park[29 * kBlockThreads] = hq.z;
+            park[30 * kBlockThreads] = hdq.x, park[31 * kBlockThreads] = hdq.y, park[32 * kBlockThreads] = hdq.z;
+            park[33 * kBlockThreads] = __uint_as_float(hit_prim);
         }
         // the hit's data as the light loops see it
         auto h_over = [&] { return AREA ? ld3(24) : over; };
         auto h_q = [&] { return AREA ? ld3(27) : hq; };
         auto h_dq = [&] { return AREA ? ld3(30) : hdq; };
-        auto h_prim = [&] { return AREA ? __float_as_uint(park[33 * 256]) : hit_prim; };
+        auto h_prim = [&] { return AREA ? __float_as_uint(park[33 * kBlockThreads]) : hit_prim; };
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             const DLight l = sc.lights[li];
             const V3 lc = v3(l.color[0], l.color[1], l.color[2]);
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                 const float inv_dist = rsq_f(dist2);
                 const float dist = dist2 * inv_dist;
                 const bool cast = has_hit && dist2 > kEps * kEps;  // null vector => lit (world.rs:77-81)
-                if (shades) phong_cell(phong_point(p_over, ld3(17), ld3(20), park[23 * 256]), lp, sum_d, sum_s);
+                if (shades) phong_cell(phong_point(p_over, ld3(17), ld3(20), park[23 * kBlockThreads]), lp, sum_d, sum_s);
                 // a light behind the surface contributes 0 x intensity (material.rs:145,161): its shadow
                 // ray cannot change the pixel and is answered without tracing
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
@@ -525,8 +534,8 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                     const float p_dqy = h_dq().y;
                     const bool gateless = !(TREE && sc.has_gates);  // a Group's box may hide a primitive from a ray
                     {
-                        const PhongBounds pb = phong_bounds(phong_point(p_over, ld3(17), ld3(20), park[23 * 256]), sh.D, sh.dlen, sh.lr, sh.cosk, sh.wide);
-                        far_front = pb.far_front, no_spec = pb.no_spec || park[13 * 256] == 0.0f;  // no specular term at all
+                        const PhongBounds pb = phong_bounds(phong_point(p_over, ld3(17), ld3(20), park[23 * kBlockThreads]), sh.D, sh.dlen, sh.lr, sh.cosk, sh.wide);
+                        far_front = pb.far_front, no_spec = pb.no_spec || park[13 * kBlockThreads] == 0.0f;  // no specular term at all
                     }
                     blockers = 0;
                     traverse<TREE>(
@@ -620,8 +629,8 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                         }
                     }
                     const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(whose < 0 ? 0 : whose);
-                    auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
-                    const PhongPoint pp = phong_point(od3(24), od3(17), od3(20), op[23 * 256]);
+                    auto od3 = [&](int k) { return v3(op[k * kBlockThreads], op[(k + 1) * kBlockThreads], op[(k + 2) * kBlockThreads]); };
+                    const PhongPoint pp = phong_point(od3(24), od3(17), od3(20), op[23 * kBlockThreads]);
                     const uint32_t per = (cells + gl - 1u) >> glog2;
                     uint32_t c = part * per;
                     uint32_t cv = c / l.usteps, cu = c - cv * l.usteps;
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                     const float got_d = shfl_f(part_d, static_cast<int>(my_rank << glog2)), got_s = shfl_f(part_s, static_cast<int>(my_rank << glog2));
                     if ((summing >> lane) & 1ull) sum_d = got_d, sum_s = got_s;
                 } else if (summing) {  // (a tile of faces turned away from the light has nothing to sum)
-                    PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * 256]);
+                    PhongPoint pp = phong_point(h_over(), ld3(17), ld3(20), park[23 * kBlockThreads]);
                     if (!shades) pp.gate = INFINITY;  // lanes without a shading point run along and are zeroed below
                     const PhongGrid pg = phong_grid(pp, l);
                     // the per-cell gates are dropped when they are known to pass (or fail) in every lane
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                         Ray sr;
                         sr.o = h_over(), sr.q = h_q(), sr.dq = h_dq(), sr.self = h_prim();
                         sr.d = v3(0.0f, 0.0f, 0.0f);
-                        const uint32_t key = __float_as_uint(park[34 * 256]);
+                        const uint32_t key = __float_as_uint(park[34 * kBlockThreads]);
                         unsigned long long occ_bits = 0ull;  // this lane's cells found occluded so far
                         bool first = true;
                         for (;;) {
@@ -753,9 +762,9 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                     uint32_t o_key, o_node;
                     {  // the owner's hit data: its LDS slots, read by every lane of its group (a broadcast)
                         const float* const op = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
-                        auto od3 = [&](int k) { return v3(op[k * 256], op[(k + 1) * 256], op[(k + 2) * 256]); };
-                        sr.o = od3(24), sr.q = od3(27), sr.dq = od3(30), sr.self = __float_as_uint(op[33 * 256]);
-                        o_key = __float_as_uint(op[34 * 256]);
+                        auto od3 = [&](int k) { return v3(op[k * kBlockThreads], op[(k + 1) * kBlockThreads], op[(k + 2) * kBlockThreads]); };
+                        sr.o = od3(24), sr.q = od3(27), sr.dq = od3(30), sr.self = __float_as_uint(op[33 * kBlockThreads]);
+                        o_key = __float_as_uint(op[34 * kBlockThreads]);
                     }
                     if (slots == 1u) {  // one owner for the whole wave: scalar broadcasts
                         const int os = __builtin_amdgcn_readfirstlane(owner);
@@ -800,19 +809,19 @@ __global__ __launch_bounds__(256, min_blocks_of(EXOTIC, TREE, AREA)) void render
                 lit *= l.inv_samples;  // light.rs:208
             }
             if (has_hit) {  // material.rs:127-161
-                const V3 ec = v3(park[8 * 256], park[9 * 256], park[10 * 256]) * lc;
-                const V3 shade = ec * (park[12 * 256] * sum_d) + lc * (park[13 * 256] * sum_s);
-                const V3 add = ec * park[11 * 256] + shade * (l.inv_samples * lit);
-                park[14 * 256] += add.x, park[15 * 256] += add.y, park[16 * 256] += add.z;
+                const V3 ec = v3(park[8 * kBlockThreads], park[9 * kBlockThreads], park[10 * kBlockThreads]) * lc;
+                const V3 shade = ec * (park[12 * kBlockThreads] * sum_d) + lc * (park[13 * kBlockThreads] * sum_s);
+                const V3 add = ec * park[11 * kBlockThreads] + shade * (l.inv_samples * lit);
+                park[14 * kBlockThreads] += add.x, park[15 * kBlockThreads] += add.y, park[16 * kBlockThreads] += add.z;
             }
         }
-        w = v3(park[0 * 256], park[1 * 256], park[2 * 256]);
-        acc = v3(park[3 * 256], park[4 * 256], park[5 * 256]);
-        n1 = park[6 * 256], n2 = park[7 * 256];
+        w = v3(park[0 * kBlockThreads], park[1 * kBlockThreads], park[2 * kBlockThreads]);
+        acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
+        n1 = park[6 * kBlockThreads], n2 = park[7 * kBlockThreads];
         nrm = ld3(17);
-        if (AREA) over = ld3(24), hq = ld3(27), hdq = ld3(30), hit_prim = __float_as_uint(park[33 * 256]);
+        if (AREA) over = ld3(24), hq = ld3(27), hdq = ld3(30), hit_prim = __float_as_uint(park[33 * kBlockThreads]);
         const V3 eye = ld3(20);
-        if (has_hit) acc = acc + w * v3(park[14 * 256], park[15 * 256], park[16 * 256]);
+        if (has_hit) acc = acc + w * v3(park[14 * kBlockThreads], park[15 * kBlockThreads], park[16 * kBlockThreads]);
 
         // ---------------------------------------------------------------- children (world.rs:59-69,94-133)
         float m_reflectivity = 0.0f, m_transparency = 0.0f;
