@@ -280,9 +280,9 @@ struct StackEntry {
 
 __device__ __forceinline__ uint32_t level_of(uint32_t node) { return 31u - static_cast<uint32_t>(__clz(static_cast<int>(node + 1u))); }
 
-// 4 waves per SIMD (<= 128 VGPRs): the kernel waits on scalar loads, cross-lane traffic and
-// transcendental latency, and measured 35 % faster at 4 waves/SIMD than at 2
-// (profiles/r01_occupancy_sweep.txt); 5 and more spill too much.
+// The kernel waits on scalar loads, cross-lane traffic and transcendental latency: it measured 35 %
+// faster at 4 waves/SIMD than at 2 early on (profiles/r01_occupancy_sweep.txt); what each
+// instantiation runs at today is chosen by min_blocks_of below.
 // EXOTIC = the scene holds cylinders or triangles (rt_math.h intersect_prim); TREE = its stream has
 // hierarchy nodes and/or Group gates (rt_pack.h) — flat scenes run an instantiation without that code.
 // The pixel of a lane: column x, row yl of this call's packed output, global row gy; false = outside.
