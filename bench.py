@@ -22,7 +22,7 @@ is assembled in rank 0's HBM inside the timed region ("strong" scaling):
   * "gather": if the shared frame cannot be set up on every rank, the packed bands go through an RCCL
               gather to rank 0 and are re-interleaved there (the round-1 path, kept as plumbing
               fallback — both paths run the same kernels).
-`RT_BENCH_SINGLE_DEVICE=1` (rehearsal on a one-GPU box) puts every rank on GPU 0 with a gloo control
+`RT_BENCH_ASSEMBLY=p2p|copy2d` overrides that choice.  `RT_BENCH_SINGLE_DEVICE=1` (rehearsal on a one-GPU box) puts every rank on GPU 0 with a gloo control
 plane; it exercises the same inter-process frame sharing without xGMI.
 
 Rank 0 prints ONE JSON line.  `value` = unique rays traced per second over the whole job
@@ -204,19 +204,10 @@ def main():
         except (OSError, AttributeError):
             hip = None
     my_rows = int(scene.output_rows(ex.camera_desc, opt))
-    band_bytes = BAND_ROWS * width * 12
-
     def move_bands(stream):
         """This rank's packed bands -> their rows of the shared frame: one strided copy (+ a last partial band)."""
-        full, tail = divmod(my_rows, BAND_ROWS)
-        dst0 = shared.ptr.value + rank * band_bytes
-        if full:
-            rc = hip.hipMemcpy2DAsync(dst0, world * band_bytes, local.data_ptr(), band_bytes, band_bytes, full, 4, stream)
-            if rc != 0:
-                raise RuntimeError(f"hipMemcpy2DAsync failed ({rc})")
-        if tail:
-            rc = hip.hipMemcpy2DAsync(dst0 + full * world * band_bytes, tail * width * 12, local.data_ptr() + full * band_bytes,
-                                      tail * width * 12, tail * width * 12, 1, 4, stream)
+        for dst, dpitch, src, spitch, wbytes, rows in partition.band_copy_plan(width, rank, world, my_rows):
+            rc = hip.hipMemcpy2DAsync(shared.ptr.value + dst, dpitch, local.data_ptr() + src, spitch, wbytes, rows, 4, stream)
             if rc != 0:
                 raise RuntimeError(f"hipMemcpy2DAsync failed ({rc})")
 
@@ -275,6 +266,9 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             took[m] = float(flag.item())
         mode = "copy2d" if took["copy2d"] < took["p2p"] else "p2p"
+        forced = os.environ.get("RT_BENCH_ASSEMBLY")  # "p2p" / "copy2d": skip the choice (rehearsals)
+        if forced in took and took[forced] < 1e29:
+            mode = forced
         calibration = {k: (v / 5 * 1e3 if v < 1e29 else None) for k, v in took.items()}
 
     for _ in range(args.warmup):

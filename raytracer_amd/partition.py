@@ -37,3 +37,23 @@ def gather_permutation(height: int, world: int) -> np.ndarray:
         perm[rows] = r * pad + np.arange(len(rows))
     assert (perm >= 0).all()
     return perm
+
+
+def band_copy_plan(width: int, rank: int, world: int, my_rows: int, bytes_per_pixel: int = 12):
+    """Strided copies that move one rank's PACKED bands to their rows of a full frame.
+
+    Returns a list of (dst_offset, dst_pitch, src_offset, src_pitch, width_bytes, height) in the sense
+    of hipMemcpy2D: `height` runs of `width_bytes` bytes, `src_pitch` apart in the packed buffer and
+    `dst_pitch` apart in the frame.  Full bands go in one copy (they lie `world` bands apart in the
+    frame); a last partial band (image height not a multiple of BAND_ROWS) in a second one.
+    """
+    band_bytes = BAND_ROWS * width * bytes_per_pixel
+    full, tail = divmod(my_rows, BAND_ROWS)
+    plan = []
+    dst0 = rank * band_bytes
+    if full:
+        plan.append((dst0, world * band_bytes, 0, band_bytes, band_bytes, full))
+    if tail:
+        n = tail * width * bytes_per_pixel
+        plan.append((dst0 + full * world * band_bytes, n, full * band_bytes, n, n, 1))
+    return plan

@@ -73,3 +73,25 @@ def test_partition_index_arithmetic():
             seen = np.concatenate([band_rows(h, partition.BAND_ROWS, r, world) for r in range(world)]) if world > 1 \
                 else np.arange(h)
             assert sorted(seen.tolist()) == list(range(h))
+
+
+@pytest.mark.parametrize("height,world", [(1080, 2), (1084, 2), (1084, 3), (540, 4), (37, 8), (8, 3), (5, 2)])
+def test_band_copy_plan_puts_every_row_where_the_gather_puts_it(height, world):
+    """bench.py's other way to assemble the frame: each rank moves its packed bands into the shared frame
+    with strided copies (hipMemcpy2D semantics, emulated here on byte arrays).  The frame must equal the
+    one the gather + permutation path builds, for heights with and without a partial last band."""
+    sys.path.insert(0, ROOT)
+    from raytracer_amd import partition
+    from raytracer_amd.capi import band_rows
+
+    width, bpp = 5, 12
+    rng = np.random.default_rng(height * 31 + world)
+    full = rng.integers(0, 255, size=(height, width * bpp), dtype=np.uint8)  # the frame, one row per image row
+    frame = np.zeros(height * width * bpp, dtype=np.uint8)
+    for rank in range(world):
+        rows = band_rows(height, partition.BAND_ROWS, rank, world)
+        packed = full[rows].reshape(-1)  # what this rank's kernel leaves in its own buffer
+        for dst, dpitch, src, spitch, wbytes, n in partition.band_copy_plan(width, rank, world, len(rows), bpp):
+            for k in range(n):
+                frame[dst + k * dpitch: dst + k * dpitch + wbytes] = packed[src + k * spitch: src + k * spitch + wbytes]
+    assert np.array_equal(frame.reshape(height, width * bpp), full)
