@@ -1,10 +1,10 @@
-//! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 1).  What `bindgen` would emit, written
+//! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 2).  What `bindgen` would emit, written
 //! by hand because the header is small and stable.  UNVERIFIED: no Rust toolchain exists in the
 //! environment this was written in; the C++ mirror of the same calls is what is compiled and tested.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 1;
+pub const RT_ABI_VERSION: u32 = 2;
 pub const RT_ITEM_NODE: u32 = 0x8000_0000;
 pub const RT_OK: c_int = 0;
 
@@ -90,6 +90,7 @@ pub struct rt_stats {
     pub light_cells: u64,
     pub pattern_lookups: u64,
     pub container_passes: u64,
+    pub shadow_rays_cast: u64,
     pub pixels: u64,
     pub kernel_ms: f32,
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -136,16 +136,25 @@ typedef struct rt_options {
  * staging copy. */
 #define RT_FLAG_GLOBAL_ROWS 1u
 
-/* Ray and work counters of one render (unique rays actually traced; the reference-equivalent
- * count, which re-traces the recursion once per light, is derived by the caller). */
+/* Ray and work counters of one render.  primary/reflection/refraction rays are traced one by one and
+ * counted once each (the reference re-traces the recursion once per light, world.rs:59-60; that
+ * reference-equivalent count is derived by the caller).  shadow_rays counts every shadow ray of the
+ * reference's accounting (light.rs:182-209: one per light cell of every shaded hit), whether the
+ * kernel cast it or ANSWERED it without casting (shaft tests, lights behind the surface, materials
+ * without diffuse and specular terms); shadow_rays_cast counts only those that were really traced
+ * against the scene.  shadow_rays_cast <= shadow_rays. */
 typedef struct rt_stats {
     uint64_t primary_rays, reflection_rays, refraction_rays, shadow_rays;
     uint64_t shaded_hits, light_cells, pattern_lookups, container_passes;
+    uint64_t shadow_rays_cast;     /* ABI 2 */
     uint64_t pixels;
     float kernel_ms;               /* hipEvent time of the render kernel(s) on the scene's stream    */
 } rt_stats;
 
-typedef struct rt_scene rt_scene; /* opaque: device-resident copy of a scene on ONE GPU */
+/* Opaque: device-resident copy of a scene on ONE GPU.  Calls that take the same rt_scene must be
+ * serialised by the caller (they share the scene's event pair and counter block); distinct scenes are
+ * independent, and the tables of a scene are never written after rt_scene_create. */
+typedef struct rt_scene rt_scene;
 
 /* Library / device. */
 uint32_t rt_abi_version(void);

@@ -1008,8 +1008,10 @@ inline uint32_t fmix32(uint32_t h) {
 // u draw (axis 0, drawn first: light.rs:215), the next byte for the v draw (axis 1)
 inline uint32_t jitter_pixel_key(uint32_t seed, uint32_t pixel) { return fmix32(pixel ^ (seed * 0x9E3779B9u)); }
 inline f64 counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, uint32_t axis) {
+    // node < 256 for RECURSION_DEPTH <= 7; deeper trees (the product allows depth 8: nodes up to 510)
+    // fold the bits the shift drops into the key, so no two nodes of a pixel share a stream
     uint32_t k = (node << 24) | (light << 16) | cell;
-    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u);
+    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u + (node >> 8) * 0x27D4EB2Fu);
     return static_cast<f64>(axis == 0 ? (h >> 24) : ((h >> 16) & 0xFFu)) / 255.0;
 }
 

@@ -55,12 +55,18 @@ class RtStats(C.Structure):
     _fields_ = [
         ("primary_rays", C.c_uint64), ("reflection_rays", C.c_uint64), ("refraction_rays", C.c_uint64),
         ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("light_cells", C.c_uint64),
-        ("pattern_lookups", C.c_uint64), ("container_passes", C.c_uint64), ("pixels", C.c_uint64),
+        ("pattern_lookups", C.c_uint64), ("container_passes", C.c_uint64), ("shadow_rays_cast", C.c_uint64),
+        ("pixels", C.c_uint64),
         ("kernel_ms", C.c_float),
     ]
 
     def total_rays(self) -> int:
+        """Rays of the reference's accounting (shadow rays answered without casting included)."""
         return int(self.primary_rays + self.reflection_rays + self.refraction_rays + self.shadow_rays)
+
+    def rays_cast(self) -> int:
+        """Rays the kernel really traced against the scene."""
+        return int(self.primary_rays + self.reflection_rays + self.refraction_rays + self.shadow_rays_cast)
 
     def as_dict(self) -> dict:
         return {name: (float(getattr(self, name)) if name == "kernel_ms" else int(getattr(self, name)))
@@ -230,6 +236,7 @@ def band_rows(vsize: int, tile_rows: int, tile_first: int = 0, tile_stride: int 
 
 
 RT_FLAG_GLOBAL_ROWS = 1
+RT_ABI_VERSION = 2
 
 
 class SharedFrame:

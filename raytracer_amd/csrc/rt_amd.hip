@@ -114,7 +114,7 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
     // sixteen instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code
-    if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), stream));
+    if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, kCounters * sizeof(unsigned long long), stream));
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
     void (*kernels[16])(const KParams) = {
         render_kernel<false, false, false, false>, render_kernel<false, false, false, true>,
@@ -159,12 +159,12 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
         (void)hipEventElapsedTime(&stats_out->kernel_ms, scene->ev0, scene->ev1);
         stats_out->pixels = static_cast<uint64_t>(rp.out_rows) * camera->hsize;
         if (stats) {
-            unsigned long long c[8] = {0};
+            unsigned long long c[kCounters] = {0};
             hipError_t e = hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(counters)");
             stats_out->primary_rays = c[0], stats_out->reflection_rays = c[1], stats_out->refraction_rays = c[2];
             stats_out->shadow_rays = c[3], stats_out->shaded_hits = c[4], stats_out->light_cells = c[5];
-            stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7];
+            stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7], stats_out->shadow_rays_cast = c[8];
         }
     }
     (void)hipFree(d_out);
@@ -221,7 +221,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {
         void* c = nullptr;
-        hipError_t e = hipMalloc(&c, 8 * sizeof(unsigned long long));
+        hipError_t e = hipMalloc(&c, kCounters * sizeof(unsigned long long));
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(counters)");
         else s->owned.push_back(c), s->counters = static_cast<unsigned long long*>(c);
     }

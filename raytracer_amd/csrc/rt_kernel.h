@@ -97,7 +97,7 @@ struct KParams {
     KScene sc;
     DCamera cam;
     float* out;
-    unsigned long long* counters;  // STATS variant only: 8 x u64
+    unsigned long long* counters;  // STATS variant only: kCounters x u64
     uint32_t max_depth, jitter_mode, seed;
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
@@ -105,6 +105,7 @@ struct KParams {
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
+constexpr int kCounters = 9;  // primary, reflect, refract, shadow, shaded, cells, pattern, container, shadow rays CAST
 
 // the builtin keeps the predicate as a lane mask (s_and with exec); __ballot() goes through a VGPR
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
-                       c_cells = 0, c_pattern = 0, c_container = 0;
+                       c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0;
 
     while (wave_any(active)) {
         // ---------------------------------------------------------------- trace (world.rs:24-41)
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
                 const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
+                if (STATS && cast && matters) c_cast++;
                 if (STATS && has_hit) c_cells++;
             } else {
                 // light.rs:192-216 + material.rs:133-161
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
                                     if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
                                 }
                                 if (hit) occ_bits |= 1ull << cell;
-                                if (STATS && first && mine && ray) c_shadow++;
+                                if (STATS && first && mine && ray) c_shadow++, c_cast++;
                                 if (++cu == l.usteps) cu = 0u, ++cv;
                             }
                             first = false;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
-                        if (STATS && cast) c_shadow++;
+                        if (STATS && cast) c_shadow++, c_cast++;
                     }
                     if (owner_now) lit = static_cast<float>(my_lit);
                 }
@@ -889,8 +891,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         }
     }
     if (STATS) {
-        unsigned long long v[8] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container};
-        for (int k = 0; k < 8; ++k) {
+        unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast};
+        for (int k = 0; k < kCounters; ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (lane == 0 && s) atomicAdd(P.counters + k, s);

@@ -1060,8 +1060,9 @@ RT_HD uint32_t fmix32(uint32_t h) {
 RT_HD uint32_t jitter_pixel_key(uint32_t seed, uint32_t pixel) { return fmix32(pixel ^ (seed * 0x9E3779B9u)); }
 // One hash per (pixel, path node, light, cell); the u draw is its top byte, the v draw the next one.
 RT_HD void counter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, float& ju, float& jv) {
+    // (node < 256 up to depth 7; the bits the shift drops at depth 8 are folded in separately)
     uint32_t k = (node << 24) | (light << 16) | cell;
-    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u);
+    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u + (node >> 8) * 0x27D4EB2Fu);
     ju = static_cast<float>(h >> 24) * (1.0f / 255.0f);
     jv = static_cast<float>((h >> 16) & 0xFFu) * (1.0f / 255.0f);
 }

@@ -151,7 +151,7 @@ def triangle_soup_desc(n: int, keep: list):
     ref, nxt = np.arange(n + 1, dtype=np.uint32), np.arange(1, n + 2, dtype=np.uint32)
     from raytracer_amd import RtSceneDesc
     d = RtSceneDesc()
-    d.abi_version = 1
+    d.abi_version = 2
     d.n_prims, d.prim_type, d.prim_inv = n + 1, types.ctypes.data, inv.ctypes.data
     d.prim_material, d.prim_param = mats.ctypes.data, params.ctypes.data
     d.n_items, d.item_ref, d.item_next = n + 1, ref.ctypes.data, nxt.ctypes.data

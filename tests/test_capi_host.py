@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     L = lib()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.rt_abi_version() == 1
+    assert L.rt_abi_version() == capi.RT_ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_header():
