@@ -99,6 +99,48 @@ int oracle_probe_pixels(const char* name, int width, int height, int jitter_mode
     }
 }
 
+// Path traces of n pixels (parity census): events[i * cap * 24 ...] receives up to `cap` events of pixel i
+// (rt_oracle.hpp kTraceEventDoubles; repeated visits of a node by the per-light re-tracing are dropped),
+// counts[i] the number stored.
+int oracle_trace_pixels(const char* name, int width, int height, int jitter_mode, uint32_t seed, const int* xy, int n,
+                        double* events, int cap, int* counts) {
+    try {
+        Scene scene;
+        if (!examples::build(name, static_cast<size_t>(width), static_cast<size_t>(height), scene))
+            return fail(std::string("unknown scene: ") + name);
+        RenderOptions opt;
+        opt.jitter = static_cast<JitterMode>(jitter_mode);
+        opt.seed = seed;
+        std::mt19937 rng(seed + 1u);
+        TraceCtx ctx;
+        ctx.mode = opt.jitter;
+        ctx.rng = &rng;
+        std::vector<f64> tr;
+        for (int i = 0; i < n; ++i) {
+            tr.clear();
+            tls_trace = &tr;
+            scene.camera.color_for_pixel(scene.world, static_cast<size_t>(xy[2 * i]), static_cast<size_t>(xy[2 * i + 1]), opt, ctx);
+            tls_trace = nullptr;
+            int stored = 0;
+            std::vector<uint32_t> seen;
+            for (size_t e = 0; e + kTraceEventDoubles <= tr.size() && stored < cap; e += kTraceEventDoubles) {
+                const uint32_t node = static_cast<uint32_t>(tr[e]);
+                bool dup = false;
+                for (uint32_t s : seen) dup |= s == node;
+                if (dup) continue;
+                seen.push_back(node);
+                std::memcpy(events + (static_cast<size_t>(i) * cap + stored) * kTraceEventDoubles, &tr[e], kTraceEventDoubles * sizeof(double));
+                ++stored;
+            }
+            counts[i] = stored;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        tls_trace = nullptr;
+        return fail(e.what());
+    }
+}
+
 // canvas.rs:31-45 quantiser on a flat f64 buffer.
 void oracle_quantize_u8(const double* rgb, size_t n, uint8_t* out) {
     for (size_t i = 0; i < n; ++i) out[i] = quantize_u8(rgb[i]);

@@ -108,6 +108,11 @@ struct RayStats {  // one "ray" = one World::intersect call in reference semanti
 // Per-thread sink for primitive-test counts (set by Camera::render workers; null = off).
 inline thread_local RayStats* tls_stats = nullptr;
 inline thread_local bool tls_debug = false;  // oracle_probe_pixels(debug): print every shaded path node
+// Path trace of one pixel for the parity census (scripts/census_classify.py): one event per shaded path
+// node — 24 doubles: node, t, point[3], normal[3], inside, n1, n2, pattern colour[3], light intensity of
+// the first four lights, reflection traced, refraction traced, shape kind, 3 spare.
+constexpr int kTraceEventDoubles = 24;
+inline thread_local std::vector<f64>* tls_trace = nullptr;
 
 // ---------------------------------------------------------------------------------------------
 // tuple.rs:74-236 — Point (w = 1) and Vector (w = 0).  The w lane is carried implicitly: every
@@ -1215,10 +1220,26 @@ struct World {
         Color acc = color::BLACK;
         if (ctx.stats) ctx.stats->shaded_hits++;
         uint32_t li = 0;
+        size_t trace_at = 0;
+        if (tls_trace) {  // census only: the decisions taken at this node (the per-light re-traces repeat them)
+            const Shape& o = *comps.intersection.object;
+            const Material& m = o.cache.material;
+            const Color pc = m.pattern.color_at(m.pattern.transform_inverse() * (o.cache.transform_inverse * comps.over_point));
+            const f64 nr = comps.n1 / comps.n2, ci = comps.eyev.dot(comps.normalv);
+            const bool tir = powi(nr, 2) * (1.0 - powi(ci, 2)) > 1.0;
+            trace_at = tls_trace->size();
+            const f64 ev[kTraceEventDoubles] = {f64(ctx.node), comps.intersection.t, comps.point.x, comps.point.y, comps.point.z,
+                                                comps.normalv.x, comps.normalv.y, comps.normalv.z, comps.inside ? 1.0 : 0.0, comps.n1, comps.n2,
+                                                pc.red, pc.green, pc.blue, -1.0, -1.0, -1.0, -1.0,
+                                                (!approx(m.reflectivity, 0.0) && depth > 0) ? 1.0 : 0.0,
+                                                (!approx(m.transparency, 0.0) && depth > 0 && !tir) ? 1.0 : 0.0, f64(int(o.kind)), 0, 0, 0};
+            tls_trace->insert(tls_trace->end(), ev, ev + kTraceEventDoubles);
+        }
         for (const auto& light : lights) {
             const Shape& object = *comps.intersection.object;
             const Material& material = object.cache.material;
             f64 light_intensity = intensity_at(light, li, comps.over_point, ctx);
+            if (tls_trace && li < 4) (*tls_trace)[trace_at + 14 + li] = light_intensity;
             Color surface = lighting(material, object, light, comps.over_point, comps.eyev, comps.normalv,
                                      light_intensity, ctx.stats);
             Color reflected = reflected_color(comps, depth, ctx);  // recomputed per light (quirk)

@@ -239,7 +239,24 @@ struct PathNode {
     uint32_t depth, node;
 };
 
-V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
+// tie-window audit (hostsim_tie_audit): nearest-hit decisions that the widened tie window
+// (rt_math.h tie_window: 1e-5 max(1, t/4)) takes differently from the reference's fixed 1e-5 window
+std::atomic<bool> g_tie_audit{false};
+std::atomic<uint64_t> g_tie_hits{0}, g_tie_differs{0}, g_tie_wide_used{0};
+Closest closest_hit_fixed_window(const Sim& s, const Ray& ray) {
+    Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
+    traverse(s, ray, 0.0f, [&] { return c.t + tie_window(c.t); }, [&](uint32_t prim, const DPrim& p) {
+        intersect_prim(p, s.ps.extras.data(), ray, prim == ray.self, [&](int, float t, float u, float v) {
+            bool better = t > 0.0f && t < c.t - kEps;
+            if (!better && c.prim != kNoPrim && t > 0.0f && fabsf(t - c.t) <= kEps) better = s.ps.order[prim] < s.ps.order[c.prim];
+            if (better && gated_in(s, prim, ray)) c = Closest{prim, t, u, v};
+        });
+        return true;
+    });
+    return c;
+}
+
+V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
     V3 acc = v3(0, 0, 0);
     if (s.ps.n_lights == 0) return acc;  // world.rs:44: fold over no lights == BLACK
     uint32_t pixel_key = jitter_pixel_key(s.seed, y * s.cam.hsize + x);
@@ -253,6 +270,10 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
     for (;;) {
         bool alive = false;
         Closest c = closest_hit(s, cur.ray);
+        if (g_tie_audit && c.prim != kNoPrim) {
+            const Closest f = closest_hit_fixed_window(s, cur.ray);
+            g_tie_hits += 1, g_tie_differs += (f.prim != c.prim) ? 1u : 0u, g_tie_wide_used += (tie_window(c.t) > kEps) ? 1u : 0u;
+        }
         if (c.prim != kNoPrim) {
             const DPrim& p = s.ps.recs[c.prim];
             const DMaterial& m = s.ps.mats[p.material];
@@ -260,6 +281,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
             V3 over = h.p + h.n * kEps;
             V3 pc = pattern_color(s.ps.pats[m.pattern], h.q + h.dq);
             V3 surface = v3(0, 0, 0);
+            double lit_by_light[4] = {-1.0, -1.0, -1.0, -1.0};
             for (uint32_t li = 0; li < s.ps.n_lights; ++li) {
                 const DLight& l = s.ps.lights[li];
                 V3 lc = v3(l.color[0], l.color[1], l.color[2]);
@@ -289,6 +311,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
                     sum_d += ldn, sum_s += spec;
                 }
                 float intensity = static_cast<float>(lit) * l.inv_samples;
+                if (li < 4) lit_by_light[li] = intensity;
                 V3 shade = ec * (m.diffuse * sum_d) + lc * (m.specular * sum_s);
                 surface = surface + ec * m.ambient + shade * (l.inv_samples * intensity);
             }
@@ -307,6 +330,12 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false) {
             if (debug) std::printf("        n1=%.6g n2=%.6g\n", n1, n2);
             V3 rdir = v3(0, 0, 0);
             if (want_refr && !refract_dir(h.eye, h.n, n1, n2, rdir)) want_refr = false;
+            if (trace) {  // census: the same 24-double event the oracle records (rt_oracle.hpp kTraceEventDoubles)
+                const double ev[24] = {double(cur.node), c.t, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, h.inside ? 1.0 : 0.0, n1, n2,
+                                       pc.x, pc.y, pc.z, lit_by_light[0], lit_by_light[1], lit_by_light[2], lit_by_light[3],
+                                       want_refl ? 1.0 : 0.0, want_refr ? 1.0 : 0.0, double(p.type), 0, 0, 0};
+                trace->insert(trace->end(), ev, ev + 24);
+            }
             float fr = use_schlick ? schlick(h.eye, h.n, n1, n2) : 0.0f;
             float k_refl = nl * m.reflectivity * (use_schlick ? fr : 1.0f);
             float k_refr = nl * m.transparency * (use_schlick ? (1.0f - fr) : 1.0f);
@@ -385,6 +414,43 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
         });
     for (auto& th : pool) th.join();
     return RT_OK;
+}
+
+// Path traces of n pixels for the parity census (same event layout as oracle_trace_pixels).
+extern "C" int hostsim_trace_pixels(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options, const int* xy,
+                                    int n, double* events, int cap, int* counts, float* rgb) {
+    Sim s;
+    std::string err;
+    int rc = pack_scene(desc, s.ps, err);
+    if (rc != RT_OK) return rc;
+    s.cam = pack_camera(*camera);
+    s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
+    s.jitter_mode = options ? options->jitter_mode : 0u;
+    s.seed = options ? options->seed : 0u;
+    std::vector<double> tr;
+    for (int i = 0; i < n; ++i) {
+        tr.clear();
+        const V3 c = trace_pixel(s, static_cast<uint32_t>(xy[2 * i]), static_cast<uint32_t>(xy[2 * i + 1]), false, &tr);
+        if (rgb) rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+        int stored = static_cast<int>(tr.size() / 24);
+        if (stored > cap) stored = cap;
+        std::memcpy(events + static_cast<size_t>(i) * cap * 24, tr.data(), static_cast<size_t>(stored) * 24 * sizeof(double));
+        counts[i] = stored;
+    }
+    return RT_OK;
+}
+
+// Renders like hostsim_render and counts how often the widened tie window of rt_math.h decides a nearest
+// hit differently from the reference's fixed 1e-5 window: out[0] = hits, out[1] = decided differently,
+// out[2] = hits whose window is wider than 1e-5 (t > 4).
+extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options, float* rgb_out,
+                                 uint64_t* out, char* err_out, int err_cap) {
+    g_tie_hits = 0, g_tie_differs = 0, g_tie_wide_used = 0;
+    g_tie_audit = true;
+    const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
+    g_tie_audit = false;
+    out[0] = g_tie_hits, out[1] = g_tie_differs, out[2] = g_tie_wide_used;
+    return rc;
 }
 
 // Renders like hostsim_render with the shaft audit switched on.  out[0] = (point, area light) pairs
