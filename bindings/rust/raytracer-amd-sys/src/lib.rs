@@ -125,6 +125,16 @@ extern "C" {
         rgb_out_host: *mut f32,
         stats_out: *mut rt_stats,
     ) -> c_int;
+    // for callers that cannot allocate: scratch in a static device array of the library
+    pub fn rt_render_stats_noalloc(
+        scene: *mut rt_scene,
+        camera: *const rt_camera_desc,
+        options: *const rt_options,
+        rgb_out_device: *mut f32,
+        stream: *mut c_void,
+        stats_out: *mut rt_stats,
+        tile_rays_out_host: *mut u32,
+    ) -> c_int;
     pub fn rt_quantize_u8_device(rgb_device: *const f32, n: usize, out_device: *mut u8, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_quantize_u8(rgb_host: *const f32, n: usize, out_host: *mut u8) -> c_int;
     // one frame shared by the GPUs of a node (rt_options.flags = RT_FLAG_GLOBAL_ROWS)
@@ -136,6 +146,7 @@ extern "C" {
 }
 
 pub const RT_FLAG_GLOBAL_ROWS: u32 = 1;
+pub const RT_NOALLOC_MAX_TILES: u32 = 131072;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

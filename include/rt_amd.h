@@ -185,6 +185,26 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_options* o
 int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
                     float* rgb_out_host, rt_stats* stats_out);
 
+/* rt_render_stats for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that may not call hipMalloc — code under HIP graph capture restrictions, tight serving
+ * loops, harnesses that forbid allocation.  Same kernel, image and counters as rt_render_stats, but
+ *   - the image goes to DEVICE memory the caller passes (rows * hsize * 3 floats, as rt_render_device);
+ *   - the kernel's scratch (counter block + per-tile ray map) lives in a static device array of the
+ *     library: RT_NOALLOC_MAX_TILES * 4 + 256 bytes held on every GPU the library runs on until the
+ *     process ends; a call whose rows make more than RT_NOALLOC_MAX_TILES tiles of 8x8 pixels
+ *     (3840x2160 = 129600 fits) is rejected with RT_ERR_CAPACITY before anything is launched;
+ *   - tile_rays_out_host (may be NULL) receives, per 8x8 tile in raster order of the call's rows
+ *     (ceil(hsize/8) per tile row), the rays that tile really traced: the cost map of the frame;
+ *   - the call enqueues on `stream`, waits for it and fills stats_out; it calls no hipMalloc/hipFree
+ *     and no allocating library routine.
+ * Every call on a GPU shares that GPU's scratch, which keeps the last call's contents (the counters
+ * are cleared on the stream at the start of each call, every tile entry is overwritten): calls that
+ * overlap on one GPU — from any scene — race and must be serialised by the caller. */
+#define RT_NOALLOC_MAX_TILES 131072u
+int rt_render_stats_noalloc(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
+                            float* rgb_out_device, void* stream, rt_stats* stats_out,
+                            uint32_t* tile_rays_out_host);
+
 /* Canvas::to_image, canvas.rs:31-45: out[i] = (rgb[i] * 255.0) as u8 — truncate toward zero,
  * saturate to 0..255, NaN -> 0.  n = number of floats. */
 int rt_quantize_u8_device(const float* rgb_device, size_t n, uint8_t* out_device, int device, void* stream);

@@ -76,7 +76,7 @@ class RtStats(C.Structure):
 # Every symbol include/rt_amd.h declares (tests check that the library exports all of them).
 RT_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
-    "rt_output_rows", "rt_render_device", "rt_render", "rt_render_stats", "rt_quantize_u8_device",
+    "rt_output_rows", "rt_render_device", "rt_render", "rt_render_stats", "rt_render_stats_noalloc", "rt_quantize_u8_device",
     "rt_quantize_u8", "rt_frame_create", "rt_frame_open", "rt_frame_close", "rt_frame_destroy", "rt_frame_download",
 ]
 
@@ -109,6 +109,8 @@ def lib() -> C.CDLL:
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
         L.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
+        L.rt_render_stats_noalloc.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p,
+                                              C.POINTER(RtStats), C.c_void_p]
         L.rt_quantize_u8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
         L.rt_quantize_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.rt_frame_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]
@@ -209,6 +211,22 @@ class Scene:
         """Enqueue Camera::render into DEVICE memory at out_ptr on `stream` (no allocation, no wait)."""
         _check(lib().rt_render_device(self._h, camera_desc, C.byref(options) if options is not None else None,
                                       C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def render_stats_noalloc(self, camera_desc, out_ptr: int, options: Optional[RtOptions] = None, stream: int = 0,
+                             want_tiles: bool = False):
+        """rt_render_stats_noalloc: image into DEVICE memory at out_ptr, counters (and the per-tile ray
+        map) through the library's static scratch; allocates nothing on the device.  Returns (RtStats,
+        tile map [tile rows, tiles per row] uint32 or None)."""
+        cam = camera_desc.contents if hasattr(camera_desc, "contents") else camera_desc
+        st = RtStats()
+        tiles = None
+        if want_tiles:
+            rows = self.output_rows(camera_desc, options)
+            tiles = np.zeros(((rows + 7) // 8, (cam.hsize + 7) // 8), dtype=np.uint32)
+        _check(lib().rt_render_stats_noalloc(self._h, camera_desc, C.byref(options) if options is not None else None,
+                                             C.c_void_p(out_ptr), C.c_void_p(stream), C.byref(st),
+                                             tiles.ctypes.data_as(C.c_void_p) if tiles is not None else None))
+        return st, tiles
 
     def close(self) -> None:
         if self._h:

@@ -81,8 +81,46 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
 
 }  // namespace
 
+// ------------------------------------------------------------------ scratch of rt_render_stats_noalloc
+// The one entry point that allocates nothing keeps its kernel's scratch — the counter block and the
+// per-tile ray map the instrumented kernel writes — in this file-scope array: every GPU the library
+// runs on holds its own copy (RT_NOALLOC_MAX_TILES * 4 + 256 bytes) until the process ends.  The
+// array's NAME is a host-side stand-in, not a device address: host code only ever uses the per-device
+// pointer hipGetSymbolAddress returned with that device current (noalloc_scratch_of).
+struct NoAllocScratch {
+    unsigned long long counters[32];          // kCounters used; 256 bytes keep the map aligned
+    uint32_t tile_rays[RT_NOALLOC_MAX_TILES];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+NoAllocScratch* g_scratch_ptr[kMaxDevices] = {};
+
+// The device's own copy of `scratch`; looked up once per device (rt_scene_create, with that device
+// current) and kept.  Returns RT_OK or a negative rt_status.
+int noalloc_scratch_of(int device, NoAllocScratch** out) {
+    static_assert(kCounters <= 32, "counter block of NoAllocScratch");
+    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_CAPACITY, "device ordinal beyond the scratch table (64 devices)");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if (cur != device) return fail(RT_ERR_BAD_ARGUMENT, "scratch lookup needs its device current");
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned null");
+        g_scratch_ptr[device] = static_cast<NoAllocScratch*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+}  // namespace
+
 struct rt_scene {
     int device = 0;
+    NoAllocScratch* scratch_ptr = nullptr;  // this device's copy of `scratch` (rt_render_stats_noalloc)
     bool exotic = false;  // some primitive is a cylinder or a triangle
     bool tree = false;    // the stream has hierarchy nodes or Group gates
     bool area = false;    // some light is an area light
@@ -95,12 +133,13 @@ struct rt_scene {
 namespace {
 
 int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt, const RenderPlan& rp, float* d_out,
-                  hipStream_t stream, bool stats) {
+                  hipStream_t stream, bool stats, unsigned long long* counters = nullptr, uint32_t* tile_rays = nullptr) {
     KParams P{};
     P.sc = s->k;
     P.cam = pack_camera(*cam);
     P.out = d_out;
-    P.counters = s->counters;
+    P.counters = counters ? counters : s->counters;
+    P.tile_rays = tile_rays;
     P.max_depth = rp.max_depth;
     P.jitter_mode = opt ? opt->jitter_mode : 0u;
     P.seed = opt ? opt->seed : 0u;
@@ -110,11 +149,11 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.tiles_x = (cam->hsize + 7u) / 8u;
     const uint32_t tiles_y = (rp.out_rows + 7u) / 8u;
     P.n_tiles = P.tiles_x * tiles_y;
+    if (stats) HIP_TRY(hipMemsetAsync(P.counters, 0, kCounters * sizeof(unsigned long long), stream));
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
     // sixteen instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code
-    if (stats) HIP_TRY(hipMemsetAsync(s->counters, 0, kCounters * sizeof(unsigned long long), stream));
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
     void (*kernels[16])(const KParams) = {
         render_kernel<false, false, false, false>, render_kernel<false, false, false, true>,
@@ -204,7 +243,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     rt_scene* s = new (std::nothrow) rt_scene;
     if (!s) return fail(RT_ERR_CAPACITY, "out of host memory");
     s->device = device;
-    rc = upload(ps.recs, &s->k.recs, s->owned);
+    rc = noalloc_scratch_of(device, &s->scratch_ptr);  // set-up time, this device current
+    if (rc == RT_OK) rc = upload(ps.recs, &s->k.recs, s->owned);
     if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
     if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
     if (rc == RT_OK) rc = upload(ps.bound, &s->k.bound, s->owned);
@@ -274,6 +314,42 @@ int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_opti
                     rt_stats* stats_out) {
     if (!stats_out) return fail(RT_ERR_BAD_ARGUMENT, "stats_out is null");
     return render_host(scene, camera, options, rgb_out_host, stats_out, true);
+}
+
+int rt_render_stats_noalloc(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
+                            float* rgb_out_device, void* stream, rt_stats* stats_out, uint32_t* tile_rays_out_host) {
+    if (!scene) return fail(RT_ERR_BAD_ARGUMENT, "scene is null");
+    if (!rgb_out_device) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
+    if (!stats_out) return fail(RT_ERR_BAD_ARGUMENT, "stats_out is null");
+    RenderPlan rp{};
+    int rc = plan_render(camera, options, rp);
+    if (rc != RT_OK) return rc;
+    const uint64_t n_tiles = static_cast<uint64_t>((camera->hsize + 7u) / 8u) * ((rp.out_rows + 7u) / 8u);
+    if (n_tiles > RT_NOALLOC_MAX_TILES)
+        return fail(RT_ERR_CAPACITY, "rt_render_stats_noalloc: " + std::to_string(n_tiles) + " tiles of 8x8 pixels exceed RT_NOALLOC_MAX_TILES (" +
+                                         std::to_string(RT_NOALLOC_MAX_TILES) + "); render row bands (rt_options.tile_*) or use rt_render_stats");
+    NoAllocScratch* const sp = scene->scratch_ptr;  // looked up in rt_scene_create, this scene's device
+    if (!sp) return fail(RT_ERR_HIP, "rt_render_stats_noalloc: the scene has no scratch pointer");
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the counters start at zero (launch_render clears them on the stream); every tile of the map is
+    // written by its wave, so the last call's map needs no clearing
+    HIP_TRY(hipEventRecord(scene->ev0, st));
+    rc = launch_render(scene, camera, options, rp, rgb_out_device, st, true, sp->counters, sp->tile_rays);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(scene->ev1, st));
+    unsigned long long c[kCounters] = {0};
+    HIP_TRY(hipMemcpyAsync(c, sp->counters, sizeof(c), hipMemcpyDeviceToHost, st));
+    if (tile_rays_out_host && n_tiles)
+        HIP_TRY(hipMemcpyAsync(tile_rays_out_host, sp->tile_rays, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memset(stats_out, 0, sizeof(*stats_out));
+    (void)hipEventElapsedTime(&stats_out->kernel_ms, scene->ev0, scene->ev1);
+    stats_out->pixels = static_cast<uint64_t>(rp.out_rows) * camera->hsize;
+    stats_out->primary_rays = c[0], stats_out->reflection_rays = c[1], stats_out->refraction_rays = c[2];
+    stats_out->shadow_rays = c[3], stats_out->shaded_hits = c[4], stats_out->light_cells = c[5];
+    stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7], stats_out->shadow_rays_cast = c[8];
+    return RT_OK;
 }
 
 int rt_quantize_u8_device(const float* rgb_device, size_t n, uint8_t* out_device, int device, void* stream) {

@@ -98,6 +98,7 @@ struct KParams {
     DCamera cam;
     float* out;
     unsigned long long* counters;  // STATS variant only: kCounters x u64
+    uint32_t* tile_rays;           // STATS variant only, may be null: rays cast per 8x8 tile, raster order of this call's rows
     uint32_t max_depth, jitter_mode, seed;
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
@@ -892,10 +893,17 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
     }
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast};
+        unsigned long long cast_rays = 0;  // primary + reflection + refraction + shadow rays really traced
         for (int k = 0; k < kCounters; ++k) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (lane == 0 && s) atomicAdd(P.counters + k, s);
+            if (k < 3 || k == 8) cast_rays += s;
+        }
+        if (P.tile_rays) {
+            uint32_t tx, tyl, tgy;
+            pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
+            if (lane == 0) P.tile_rays[(tyl >> 3) * P.tiles_x + (tx >> 3)] = static_cast<uint32_t>(cast_rays);
         }
     }
 }
