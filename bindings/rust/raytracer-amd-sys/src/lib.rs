@@ -91,6 +91,7 @@ pub struct rt_stats {
     pub pattern_lookups: u64,
     pub container_passes: u64,
     pub shadow_rays_cast: u64,
+    pub exact_nodes: u64,
     pub pixels: u64,
     pub kernel_ms: f32,
 }

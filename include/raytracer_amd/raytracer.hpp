@@ -443,6 +443,7 @@ struct FlatScene {
     std::vector<float> prim_inv, prim_param, node_min, node_max, mat_param, pat_color_a, pat_color_b, pat_inv;
     std::vector<float> light_pos, light_uvec, light_vvec, light_color;
     std::vector<uint32_t> prim_material, item_ref, item_next, mat_pattern, light_usteps, light_vsteps;
+    std::vector<double> prim_inv64, prim_param64, mat_ior64, pat_inv64;  // the f64 values themselves (rt_exact.h)
 
     rt_scene_desc desc() const {
         rt_scene_desc d{};
@@ -463,6 +464,8 @@ struct FlatScene {
         d.light_type = light_type.data(), d.light_pos = light_pos.data(), d.light_uvec = light_uvec.data();
         d.light_vvec = light_vvec.data(), d.light_usteps = light_usteps.data(), d.light_vsteps = light_vsteps.data();
         d.light_color = light_color.data();
+        d.prim_inv64 = prim_inv64.data(), d.prim_param64 = prim_param64.data();
+        d.mat_ior64 = mat_ior64.data(), d.pat_inv64 = pat_inv64.data();
         return d;
     }
 };
@@ -475,6 +478,10 @@ inline void push_affine(std::vector<float>& v, const Transform& t) {
     if (!t.is_affine()) throw Error("transform is not affine");
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 4; ++j) v.push_back(static_cast<float>(t.m[i][j]));
+}
+inline void push_affine64(std::vector<double>& v, const Transform& t) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) v.push_back(t.m[i][j]);
 }
 inline bool same_color(const Color& a, const Color& b) { return a.red == b.red && a.green == b.green && a.blue == b.blue; }
 inline bool same_transform(const Transform& a, const Transform& b) { return a.m == b.m; }
@@ -499,10 +506,12 @@ struct Flattener {
             push3(out.pat_color_a, p.solid.red, p.solid.green, p.solid.blue);
             push3(out.pat_color_b, p.solid.red, p.solid.green, p.solid.blue);
             push_affine(out.pat_inv, Transform{});
+            push_affine64(out.pat_inv64, Transform{});
         } else {
             push3(out.pat_color_a, p.spec.color_a.red, p.spec.color_a.green, p.spec.color_a.blue);
             push3(out.pat_color_b, p.spec.color_b.red, p.spec.color_b.green, p.spec.color_b.blue);
             push_affine(out.pat_inv, p.spec.transform_inverse);
+            push_affine64(out.pat_inv64, p.spec.transform_inverse);
         }
         return static_cast<uint32_t>(pats.size() - 1);
     }
@@ -519,6 +528,7 @@ struct Flattener {
         out.mat_pattern.push_back(pi);
         const double p[8] = {m.ambient, m.diffuse, m.specular, m.shininess, m.index_of_refraction, m.reflectivity, m.transparency, 0.0};
         for (double v : p) out.mat_param.push_back(static_cast<float>(v));
+        out.mat_ior64.push_back(m.index_of_refraction);
         return static_cast<uint32_t>(mats.size() - 1);
     }
     void add_shape(const Shape& s) {
@@ -548,17 +558,21 @@ struct Flattener {
         }
         out.prim_type.push_back(static_cast<uint8_t>(type));
         push_affine(out.prim_inv, s.transform_inverse);
+        push_affine64(out.prim_inv64, s.transform_inverse);
         out.prim_material.push_back(material_index(s.material));
         size_t base = out.prim_param.size();
         out.prim_param.resize(base + 24, 0.0f);
+        out.prim_param64.resize(base + 24, 0.0);
         float* p = out.prim_param.data() + base;
+        double* p64 = out.prim_param64.data() + base;
         if (s.kind == Shape::CYLINDER) {
             p[0] = static_cast<float>(s.cyl_min), p[1] = static_cast<float>(s.cyl_max), p[2] = s.closed ? 1.0f : 0.0f;
+            p64[0] = s.cyl_min, p64[1] = s.cyl_max, p64[2] = s.closed ? 1.0 : 0.0;
         } else if (s.kind == Shape::TRIANGLE || s.kind == Shape::SMOOTH_TRIANGLE) {
             const double v[21] = {s.v0.x, s.v0.y, s.v0.z, s.e0.x, s.e0.y, s.e0.z, s.e1.x, s.e1.y, s.e1.z,
                                   s.normal.x, s.normal.y, s.normal.z, s.n0.x, s.n0.y, s.n0.z,
                                   s.n1.x, s.n1.y, s.n1.z, s.n2.x, s.n2.y, s.n2.z};
-            for (int i = 0; i < 21; ++i) p[i] = static_cast<float>(v[i]);
+            for (int i = 0; i < 21; ++i) p[i] = static_cast<float>(v[i]), p64[i] = v[i];
         }
         out.item_ref.push_back(prim);
         out.item_next.push_back(static_cast<uint32_t>(out.item_ref.size()));
@@ -628,6 +642,10 @@ struct Camera {
         d.half_width = static_cast<float>(half_width), d.half_height = static_cast<float>(half_height);
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 4; ++j) d.inv[i * 4 + j] = static_cast<float>(transform_inverse.m[i][j]);
+        d.has_f64 = 1u;
+        d.pixel_size64 = pixel_size, d.half_width64 = half_width, d.half_height64 = half_height;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) d.inv64[i * 4 + j] = transform_inverse.m[i][j];
         return d;
     }
     // camera.rs:163-208.  `device` is the HIP ordinal; options default to the reference's constants.

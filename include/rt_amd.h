@@ -106,6 +106,16 @@ typedef struct rt_scene_desc {
     const uint32_t* light_usteps;  /* [n_lights]     1 for point lights                              */
     const uint32_t* light_vsteps;  /* [n_lights]                                                     */
     const float* light_color;      /* [n_lights][3]  intensity                                       */
+
+    /* Optional (ABI 2): the caller's own f64 values of the tables the hit geometry hangs on — all four
+     * or none (NULL).  With them (and rt_camera_desc.has_f64) the kernels carry every path ray a second
+     * time in f64 and work the hits that decide something out again with the reference's formulas
+     * (raytracer_amd/csrc/rt_exact.h): pattern boundaries, silhouettes, exact ties and deep glass paths
+     * then follow the f64 reference instead of FP32 rounding.  Without them the path is FP32 only. */
+    const double* prim_inv64;      /* [n_prims][12]  transform_inverse, object.rs:9                  */
+    const double* prim_param64;    /* [n_prims][24]  same layout as prim_param                       */
+    const double* mat_ior64;       /* [n_materials]  index_of_refraction                             */
+    const double* pat_inv64;       /* [n_patterns][12]                                               */
 } rt_scene_desc;
 
 /* Camera, camera.rs:64-73 after Camera::try_from (camera.rs:95-136). */
@@ -113,6 +123,9 @@ typedef struct rt_camera_desc {
     uint32_t hsize, vsize;
     float pixel_size, half_width, half_height;
     float inv[12];                 /* transform_inverse, first three rows                            */
+    uint32_t has_f64;              /* nonzero: the four fields below hold the caller's f64 values    */
+    double pixel_size64, half_width64, half_height64;
+    double inv64[12];
 } rt_camera_desc;
 
 /* Row tiles for multi-GPU partitioning: the image is cut into bands of `tile_rows` pixel rows;
@@ -135,6 +148,9 @@ typedef struct rt_options {
  * (camera.rs:183-205 collects rows through a Mutex<Canvas>) without a collective and without a
  * staging copy. */
 #define RT_FLAG_GLOBAL_ROWS 1u
+/* Render with the FP32 path only even though the scene and the camera carry f64 tables (timing the
+ * f64 chain's share, parity experiments). */
+#define RT_FLAG_F32_ONLY 2u
 
 /* Ray and work counters of one render.  primary/reflection/refraction rays are traced one by one and
  * counted once each (the reference re-traces the recursion once per light, world.rs:59-60; that
@@ -147,6 +163,7 @@ typedef struct rt_stats {
     uint64_t primary_rays, reflection_rays, refraction_rays, shadow_rays;
     uint64_t shaded_hits, light_cells, pattern_lookups, container_passes;
     uint64_t shadow_rays_cast;     /* ABI 2 */
+    uint64_t exact_nodes;          /* ABI 2: path nodes worked out again in f64 (rt_scene_desc.*64)  */
     uint64_t pixels;
     float kernel_ms;               /* hipEvent time of the render kernel(s) on the scene's stream    */
 } rt_stats;

@@ -32,6 +32,7 @@ class RtSceneDesc(C.Structure):
         ("n_lights", C.c_uint32), ("light_type", C.c_void_p), ("light_pos", C.c_void_p),
         ("light_uvec", C.c_void_p), ("light_vvec", C.c_void_p), ("light_usteps", C.c_void_p),
         ("light_vsteps", C.c_void_p), ("light_color", C.c_void_p),
+        ("prim_inv64", C.c_void_p), ("prim_param64", C.c_void_p), ("mat_ior64", C.c_void_p), ("pat_inv64", C.c_void_p),
     ]
 
 
@@ -40,6 +41,9 @@ class RtCameraDesc(C.Structure):
         ("hsize", C.c_uint32), ("vsize", C.c_uint32),
         ("pixel_size", C.c_float), ("half_width", C.c_float), ("half_height", C.c_float),
         ("inv", C.c_float * 12),
+        ("has_f64", C.c_uint32),
+        ("pixel_size64", C.c_double), ("half_width64", C.c_double), ("half_height64", C.c_double),
+        ("inv64", C.c_double * 12),
     ]
 
 
@@ -56,7 +60,7 @@ class RtStats(C.Structure):
         ("primary_rays", C.c_uint64), ("reflection_rays", C.c_uint64), ("refraction_rays", C.c_uint64),
         ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("light_cells", C.c_uint64),
         ("pattern_lookups", C.c_uint64), ("container_passes", C.c_uint64), ("shadow_rays_cast", C.c_uint64),
-        ("pixels", C.c_uint64),
+        ("exact_nodes", C.c_uint64), ("pixels", C.c_uint64),
         ("kernel_ms", C.c_float),
     ]
 
@@ -254,6 +258,7 @@ def band_rows(vsize: int, tile_rows: int, tile_first: int = 0, tile_stride: int 
 
 
 RT_FLAG_GLOBAL_ROWS = 1
+RT_FLAG_F32_ONLY = 2
 RT_ABI_VERSION = 2
 
 

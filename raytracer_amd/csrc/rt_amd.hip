@@ -47,7 +47,7 @@ int upload(const std::vector<T>& v, const T** out, std::vector<void*>& owned) {
 
 struct RenderPlan {
     uint32_t max_depth, tile_rows, tile_first, tile_stride, out_rows;
-    bool global_rows;
+    bool global_rows, f32_only;
 };
 
 int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp) {
@@ -56,8 +56,9 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
     if (static_cast<uint64_t>(cam->hsize) * cam->vsize > 0x7FFFFFFFull) return fail(RT_ERR_CAPACITY, "image too large");
     rt_options o{};
     if (opt) o = *opt;
-    if (o.flags & ~RT_FLAG_GLOBAL_ROWS) return fail(RT_ERR_BAD_ARGUMENT, "options.flags holds an unknown bit");
+    if (o.flags & ~(RT_FLAG_GLOBAL_ROWS | RT_FLAG_F32_ONLY)) return fail(RT_ERR_BAD_ARGUMENT, "options.flags holds an unknown bit");
     rp.global_rows = (o.flags & RT_FLAG_GLOBAL_ROWS) != 0;
+    rp.f32_only = (o.flags & RT_FLAG_F32_ONLY) != 0;
     if (o.jitter_mode > RT_JITTER_COUNTER) return fail(RT_ERR_UNSUPPORTED, "unknown jitter mode");
     rp.max_depth = o.max_depth ? o.max_depth : 5u;
     if (rp.max_depth > RT_MAX_DEPTH) return fail(RT_ERR_CAPACITY, "max_depth exceeds RT_MAX_DEPTH");
@@ -124,6 +125,7 @@ struct rt_scene {
     bool exotic = false;  // some primitive is a cylinder or a triangle
     bool tree = false;    // the stream has hierarchy nodes or Group gates
     bool area = false;    // some light is an area light
+    bool has_f64 = false; // the caller gave the f64 tables of the exact chain (rt_exact.h)
     KScene k{};
     std::vector<void*> owned;
     unsigned long long* counters = nullptr;
@@ -137,6 +139,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     KParams P{};
     P.sc = s->k;
     P.cam = pack_camera(*cam);
+    const bool exact = s->has_f64 && cam->has_f64 != 0 && !rp.f32_only;
+    if (exact) P.cam64 = pack_camera64(*cam);
     P.out = d_out;
     P.counters = counters ? counters : s->counters;
     P.tile_rays = tile_rays;
@@ -153,18 +157,21 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
-    // sixteen instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code
+    // 32 instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
-    void (*kernels[16])(const KParams) = {
-        render_kernel<false, false, false, false>, render_kernel<false, false, false, true>,
-        render_kernel<false, false, true, false>,  render_kernel<false, false, true, true>,
-        render_kernel<false, true, false, false>,  render_kernel<false, true, false, true>,
-        render_kernel<false, true, true, false>,   render_kernel<false, true, true, true>,
-        render_kernel<true, false, false, false>,  render_kernel<true, false, false, true>,
-        render_kernel<true, false, true, false>,   render_kernel<true, false, true, true>,
-        render_kernel<true, true, false, false>,   render_kernel<true, true, false, true>,
-        render_kernel<true, true, true, false>,    render_kernel<true, true, true, true>};
-    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
+#define RT_KERNELS(X)                                                                                      \
+    {render_kernel<false, false, false, false, X>, render_kernel<false, false, false, true, X>,           \
+     render_kernel<false, false, true, false, X>,  render_kernel<false, false, true, true, X>,            \
+     render_kernel<false, true, false, false, X>,  render_kernel<false, true, false, true, X>,            \
+     render_kernel<false, true, true, false, X>,   render_kernel<false, true, true, true, X>,             \
+     render_kernel<true, false, false, false, X>,  render_kernel<true, false, false, true, X>,            \
+     render_kernel<true, false, true, false, X>,   render_kernel<true, false, true, true, X>,             \
+     render_kernel<true, true, false, false, X>,   render_kernel<true, true, false, true, X>,             \
+     render_kernel<true, true, true, false, X>,    render_kernel<true, true, true, true, X>}
+    void (*const kernels_f32[16])(const KParams) = RT_KERNELS(false);
+    void (*const kernels_f64[16])(const KParams) = RT_KERNELS(true);
+#undef RT_KERNELS
+    hipLaunchKernelGGL((exact ? kernels_f64 : kernels_f32)[variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -204,6 +211,7 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
             stats_out->primary_rays = c[0], stats_out->reflection_rays = c[1], stats_out->refraction_rays = c[2];
             stats_out->shadow_rays = c[3], stats_out->shaded_hits = c[4], stats_out->light_cells = c[5];
             stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7], stats_out->shadow_rays_cast = c[8];
+            stats_out->exact_nodes = c[9];
         }
     }
     (void)hipFree(d_out);
@@ -253,8 +261,14 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
     if (rc == RT_OK) rc = upload(ps.pats, &s->k.pats, s->owned);
     if (rc == RT_OK) rc = upload(ps.lights, &s->k.lights, s->owned);
+    if (rc == RT_OK) rc = upload(ps.xprims, &s->k.xprims, s->owned);
+    if (rc == RT_OK) rc = upload(ps.xextras, &s->k.xextras, s->owned);
+    if (rc == RT_OK) rc = upload(ps.xior, &s->k.xior, s->owned);
+    if (rc == RT_OK) rc = upload(ps.xpats, &s->k.xpats, s->owned);
+    s->has_f64 = ps.has_f64;
     s->k.n_items = ps.n_items;
     s->k.has_gates = ps.has_gates, s->k.has_bvh = ps.has_bvh;
+    s->k.any_spawn = ps.any_spawn ? 1u : 0u;
     s->exotic = ps.exotic;
     s->tree = ps.has_bvh || ps.has_gates;
     s->area = ps.has_area;
@@ -349,6 +363,7 @@ int rt_render_stats_noalloc(rt_scene* scene, const rt_camera_desc* camera, const
     stats_out->primary_rays = c[0], stats_out->reflection_rays = c[1], stats_out->refraction_rays = c[2];
     stats_out->shadow_rays = c[3], stats_out->shaded_hits = c[4], stats_out->light_cells = c[5];
     stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7], stats_out->shadow_rays_cast = c[8];
+    stats_out->exact_nodes = c[9];
     return RT_OK;
 }
 

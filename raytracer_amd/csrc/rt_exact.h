@@ -1,0 +1,343 @@
+// rt_exact.h — the f64 geometry chain of the render kernels ("exact chain").
+//
+// FP32 meets the f64 reference at 1e-4 almost everywhere (rt_math.h), but not where colour is
+// discontinuous in position (pattern boundaries, silhouettes, the corner line of two walls) and not
+// along deep glass paths, where every curved interface magnifies the 1e-6 position error of an FP32
+// world coordinate (the round-2 parity census: 5e-4 of C4's pixels at 4K, profiles/
+// r02_parity_census_before.txt).  The kernels therefore carry every PATH ray (camera, reflection,
+// refraction) a second time as f64 origin + direction, and at a path node that needs it — it spawns
+// children, its pattern lookup lands within FP32 error of a boundary, or the FP32 nearest-hit
+// search saw a second candidate it could not tell apart — the hit is worked out again in f64 from
+// the f64 ray and the f64 tables of the caller's scene, with the REFERENCE'S OWN formulas in the
+// reference's operation order (no FMA contraction: the library is built with -ffp-contract=off):
+// ray.rs:17-22 + matrix.rs:184-198 (fold from 0.0), sphere.rs:38-72, plane.rs:39-51, cube.rs:39-122,
+// cylinder.rs:126-225, triangle.rs:104-133, intersection.rs:40-69,105-120, shape.rs:83-96,
+// pattern.rs:58-96, world.rs:94-133.  The FP32 machinery keeps doing the bulk work — hierarchy walks,
+// candidate search, shadow rays, Phong sums — and the chain only replaces the handful of quantities the
+// decisions hang on, so a refined node reproduces the reference's t, hit point, normal, pattern
+// cell and child rays to the last bit (given the same candidates), including the exact ties the
+// reference itself decides by its rounding noise (a camera in the symmetry plane of two walls).
+//
+// Everything is RT_HD: the scalar executable spec (tests/cpp/hostsim.cpp) compiles the same text.
+#pragma once
+
+#include "rt_math.h"
+
+namespace rtk {
+
+struct D3 {
+    double x, y, z;
+};
+RT_HD D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+RT_HD D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }  // tuple.rs:208-218
+RT_HD D3 xneg(D3 a) { return D3{0.0 - a.x, 0.0 - a.y, 0.0 - a.z}; }          // tuple.rs:200-206: 0 - v
+RT_HD double xdot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // tuple.rs:107-109
+RT_HD D3 xcross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_HD V3 to_v3(D3 a) { return V3{static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(a.z)}; }
+RT_HD D3 to_d3(V3 a) { return D3{a.x, a.y, a.z}; }
+
+constexpr double kEpsD = 1e-5;  // float.rs:3
+RT_HD bool xapprox(double a, double b) {  // float.rs:5-11
+    if (isinf(a) && isinf(b)) return a == b;
+    return fabs(a - b) <= kEpsD;
+}
+RT_HD bool xge(double a, double b) { return xapprox(a, b) || a > b; }
+RT_HD bool xle(double a, double b) { return xapprox(a, b) || a < b; }
+// partial_cmp == Greater (float.rs:29-37: NaN falls through to Greater)
+RT_HD bool xgreater(double a, double b) { return !xapprox(a, b) && !(a < b); }
+
+// matrix.rs:184-198 on the first three rows of an affine matrix (the fourth is 0 0 0 1): each
+// component is the fold 0.0 + m0 x + m1 y + m2 z + m3 w, left to right.
+RT_HD D3 xpoint(const double* m, D3 p) {
+    return D3{(((0.0 + m[0] * p.x) + m[1] * p.y) + m[2] * p.z) + m[3] * 1.0, (((0.0 + m[4] * p.x) + m[5] * p.y) + m[6] * p.z) + m[7] * 1.0,
+              (((0.0 + m[8] * p.x) + m[9] * p.y) + m[10] * p.z) + m[11] * 1.0};
+}
+RT_HD D3 xvector(const double* m, D3 v) {
+    return D3{(((0.0 + m[0] * v.x) + m[1] * v.y) + m[2] * v.z) + m[3] * 0.0, (((0.0 + m[4] * v.x) + m[5] * v.y) + m[6] * v.z) + m[7] * 0.0,
+              (((0.0 + m[8] * v.x) + m[9] * v.y) + m[10] * v.z) + m[11] * 0.0};
+}
+// transform_inverse.transpose() * normal (shape.rs:89-90); the transposed matrix's fourth column is the
+// inverse's fourth row (0 0 0 1), times the vector's w = 0
+RT_HD D3 xnormal(const double* m, D3 n) {
+    return D3{(((0.0 + m[0] * n.x) + m[4] * n.y) + m[8] * n.z) + 0.0 * 0.0, (((0.0 + m[1] * n.x) + m[5] * n.y) + m[9] * n.z) + 0.0 * 0.0,
+              (((0.0 + m[2] * n.x) + m[6] * n.y) + m[10] * n.z) + 0.0 * 0.0};
+}
+RT_HD double xmagnitude(D3 v) { return sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }  // tuple.rs:92-94
+// tuple.rs:102-104,228-236: v * (1 / |v|); false for |v| <= eps
+RT_HD bool xnormalize(D3 v, D3& out) {
+    const double m = xmagnitude(v);
+    if (xapprox(m, 0.0)) return false;
+    out = v * (1.0 / m);
+    return true;
+}
+
+// The caller's scene in f64 (rt_scene_desc.*64), in stream order (rt_pack.h).
+struct XPrim {  // per stream record (hierarchy nodes: unused)
+    double inv[12];
+};
+struct XExtra {  // cylinder {min, max, closed}; triangle {v0, e0, e1, normal, n0, n1, n2}
+    double f[24];
+};
+struct XPattern {
+    double inv[12];
+};
+struct XCamera {
+    double pixel_size, half_width, half_height;
+    double inv[12];
+};
+
+// camera.rs:210-228
+RT_HD void xcamera_ray(const XCamera& c, uint32_t x, uint32_t y, D3& origin, D3& dir) {
+    const double xoffset = (static_cast<double>(x) + 0.5) * c.pixel_size;
+    const double yoffset = (static_cast<double>(y) + 0.5) * c.pixel_size;
+    const double world_x = c.half_width - xoffset, world_y = c.half_height - yoffset;
+    const D3 pixel = xpoint(c.inv, d3(world_x, world_y, -1.0));
+    origin = xpoint(c.inv, d3(0.0, 0.0, 0.0));
+    D3 n = d3(0.0, 0.0, 0.0);
+    xnormalize(pixel - origin, n);
+    dir = n;
+}
+
+// The intersections of ONE primitive with the f64 ray, in the order the reference pushes them.
+struct XHits {
+    double t[4], u, v;
+    int n;
+};
+// cube.rs:79-97
+RT_HD void xcheck_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
+    const double tmin_num = mn - origin, tmax_num = mx - origin;
+    if (xge(fabs(direction), kEpsD)) {  // approximate ge: true for every finite direction
+        tmin = tmin_num / direction;
+        tmax = tmax_num / direction;
+    } else {
+        tmin = tmin_num * static_cast<double>(INFINITY);
+        tmax = tmax_num * static_cast<double>(INFINITY);
+    }
+    if (tmin > tmax) {
+        const double s = tmin;
+        tmin = tmax, tmax = s;
+    }
+}
+RT_HD double xmax_by3(double a, double b, double c) {  // Iterator::max_by: the LAST of approximately equal maxima
+    double m = xgreater(a, b) ? a : b;
+    return xgreater(m, c) ? m : c;
+}
+RT_HD double xmin_by3(double a, double b, double c) {  // Iterator::min_by: the FIRST of approximately equal minima
+    double m = xgreater(a, b) ? b : a;
+    return xgreater(m, c) ? c : m;
+}
+RT_HD bool xcheck_cap(D3 o, D3 d, double t) {  // cylinder.rs:220-225
+    const double x = o.x + t * d.x, z = o.z + t * d.z;
+    return xle(x * x + z * z, 1.0);
+}
+RT_HD void xcaps(D3 o, D3 d, double ymin, double ymax, bool closed, XHits& h) {  // cylinder.rs:186-217
+    if (!closed || xapprox(d.y, 0.0)) return;
+    double t = (ymin - o.y) / d.y;
+    if (xcheck_cap(o, d, t)) h.t[h.n++] = t;
+    t = (ymax - o.y) / d.y;
+    if (xcheck_cap(o, d, t)) h.t[h.n++] = t;
+}
+// EXOTIC = false compiles the cylinder / triangle code out (rt_math.h intersect_prim does the same).
+template <bool EXOTIC = true>
+RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro, D3 rd) {
+    XHits h;
+    h.n = 0, h.u = 0.0, h.v = 0.0;
+    h.t[0] = h.t[1] = h.t[2] = h.t[3] = 0.0;
+    const D3 o = xpoint(inv, ro), d = xvector(inv, rd);  // shape.rs:79-81, ray.rs:17-22
+    switch (type) {
+        case PRIM_SPHERE: {  // sphere.rs:38-72
+            const double a = xdot(d, d);
+            const double b = 2.0 * xdot(d, o);
+            const double c = xdot(o, o) - 1.0;
+            const double disc = b * b - 4.0 * a * c;
+            if (disc < 0.0) break;
+            h.t[0] = (-b - sqrt(disc)) / (2.0 * a);
+            h.t[1] = (-b + sqrt(disc)) / (2.0 * a);
+            h.n = 2;
+            break;
+        }
+        case PRIM_PLANE:  // plane.rs:39-51
+            if (!xapprox(d.y, 0.0)) h.t[0] = -o.y / d.y, h.n = 1;
+            break;
+        case PRIM_CUBE: {  // cube.rs:39-76,101-122
+            double x0, x1, y0, y1, z0, z1;
+            xcheck_axis(o.x, d.x, -1.0, 1.0, x0, x1);
+            xcheck_axis(o.y, d.y, -1.0, 1.0, y0, y1);
+            xcheck_axis(o.z, d.z, -1.0, 1.0, z0, z1);
+            const double tmin = xmax_by3(x0, y0, z0), tmax = xmin_by3(x1, y1, z1);
+            if (tmin > tmax) break;
+            h.t[0] = tmin, h.t[1] = tmax, h.n = 2;
+            break;
+        }
+        case PRIM_CYLINDER: {  // cylinder.rs:126-170
+            if (!EXOTIC) break;
+            const double ymin = e[0], ymax = e[1];
+            const bool closed = e[2] != 0.0;
+            const double a = d.x * d.x + d.z * d.z;
+            if (xapprox(a, 0.0)) {
+                xcaps(o, d, ymin, ymax, closed, h);
+                break;
+            }
+            const double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+            const double c = o.x * o.x + o.z * o.z - 1.0;
+            const double disc = b * b - 4.0 * a * c;
+            if (disc < 0.0) break;
+            double t0 = (-b - sqrt(disc)) / (2.0 * a), t1 = (-b + sqrt(disc)) / (2.0 * a);
+            if (t0 > t1) {
+                const double s = t0;
+                t0 = t1, t1 = s;
+            }
+            const double y0 = o.y + t0 * d.y;
+            if (ymin < y0 && y0 < ymax) h.t[h.n++] = t0;
+            const double y1 = o.y + t1 * d.y;
+            if (ymin < y1 && y1 < ymax) h.t[h.n++] = t1;
+            xcaps(o, d, ymin, ymax, closed, h);
+            break;
+        }
+        default: {  // triangle.rs:104-133 (smooth triangles intersect alike, smooth_triangle.rs:22-24)
+            if (!EXOTIC) break;
+            const D3 v0 = d3(e[0], e[1], e[2]), e0 = d3(e[3], e[4], e[5]), e1 = d3(e[6], e[7], e[8]);
+            const D3 dir_cross_e1 = xcross(d, e1);
+            const double det = xdot(e0, dir_cross_e1);
+            if (xapprox(fabs(det), 0.0)) break;
+            const double f = 1.0 / det;
+            const D3 p0 = o - v0;
+            const double u = f * xdot(p0, dir_cross_e1);
+            if (!(u >= 0.0 && u <= 1.0)) break;
+            const D3 oxe0 = xcross(p0, e0);
+            const double v = f * xdot(d, oxe0);
+            if (v < 0.0 || (u + v) > 1.0) break;
+            h.t[0] = f * xdot(e1, oxe0), h.u = u, h.v = v, h.n = 1;
+            break;
+        }
+    }
+    return h;
+}
+
+// Intersection::sort + hit (intersection.rs:105-120) over the intersections of up to two candidate
+// primitives, entered in world.objects order: approximate comparator, insertion sort (stable), the
+// first t > 0.0 wins.  K slots per primitive (2 without cylinders; absent = +inf, which sorts last and
+// never wins); every index is a compile-time constant so that the lists stay in registers.
+template <int K>
+struct XCandidates {
+    static constexpr int N = 2 * K;
+    double t[N], u[2], v[2];
+    uint32_t prim[2];
+    int who[N];  // which of the two primitives an entry belongs to
+    RT_HD XCandidates() {
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = static_cast<double>(INFINITY), who[i] = i / K;
+        prim[0] = prim[1] = kNoPrim, u[0] = u[1] = v[0] = v[1] = 0.0;
+    }
+    RT_HD void set(int which, const XHits& h, uint32_t prim_id) {  // which = 0 first, then 1
+        prim[which] = prim_id, u[which] = h.u, v[which] = h.v;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (k < h.n) t[which * K + k] = h.t[k];
+    }
+    RT_HD bool hit(double& t_out, uint32_t& prim_out, double& u_out, double& v_out) {
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double kt = t[i];
+            const int kw = who[i];
+            bool moving = true;
+#pragma unroll
+            for (int j = i; j > 0; --j) {
+                const bool shift = moving && (!xapprox(kt, t[j - 1]) && kt < t[j - 1]);
+                if (shift) t[j] = t[j - 1], who[j] = who[j - 1];
+                else if (moving) t[j] = kt, who[j] = kw, moving = false;
+            }
+            if (moving) t[0] = kt, who[0] = kw;
+        }
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (!found && t[i] > 0.0 && t[i] < static_cast<double>(INFINITY)) {
+                found = true;
+                t_out = t[i], prim_out = who[i] ? prim[1] : prim[0], u_out = who[i] ? u[1] : u[0], v_out = who[i] ? v[1] : v[0];
+            }
+        return found;
+    }
+};
+
+// intersection.rs:40-69 + shape.rs:83-96,118-137 + the shapes' local normals
+struct XHit {
+    D3 point, normal, eye, reflectv, over, under;
+    bool inside;
+};
+template <bool EXOTIC = true>
+RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3 rd, double t, double hu, double hv) {
+    XHit h;
+    h.point = ro + rd * t;  // ray.rs:13-15
+    h.eye = xneg(rd);
+    const D3 p = xpoint(inv, h.point);
+    D3 nobj = d3(0.0, 1.0, 0.0);
+    switch (type) {
+        case PRIM_SPHERE: nobj = p - d3(0.0, 0.0, 0.0); break;  // sphere.rs:74-76
+        case PRIM_PLANE: nobj = d3(0.0, 1.0, 0.0); break;       // plane.rs:53-55
+        case PRIM_CUBE: {                                       // cube.rs:125-141
+            const double ax = fabs(p.x), ay = fabs(p.y), az = fabs(p.z);
+            double mc = (ax > ay) ? ax : ay;  // max_by with the exact comparison: the largest value
+            mc = (mc > az) ? mc : az;
+            if (xapprox(mc, ax)) nobj = d3(p.x, 0.0, 0.0);
+            else if (xapprox(mc, ay)) nobj = d3(0.0, p.y, 0.0);
+            else nobj = d3(0.0, 0.0, p.z);
+            break;
+        }
+        case PRIM_CYLINDER: {  // cylinder.rs:172-184
+            if (!EXOTIC) break;
+            const double dist = p.x * p.x + p.z * p.z;
+            if (dist < 1.0 && xge(p.y, e[1] - kEpsD)) nobj = d3(0.0, 1.0, 0.0);
+            else if (dist < 1.0 && xle(p.y, e[0] + kEpsD)) nobj = d3(0.0, -1.0, 0.0);
+            else nobj = d3(p.x, 0.0, p.z);
+            break;
+        }
+        case PRIM_TRIANGLE:  // triangle.rs:135-137
+            if (EXOTIC) nobj = d3(e[9], e[10], e[11]);
+            break;
+        default: {  // smooth_triangle.rs:26-33
+            if (!EXOTIC) break;
+            const D3 n0 = d3(e[12], e[13], e[14]), n1 = d3(e[15], e[16], e[17]), n2 = d3(e[18], e[19], e[20]);
+            nobj = n1 * hu + n2 * hv + n0 * (1.0 - hu - hv);
+            break;
+        }
+    }
+    D3 n = d3(0.0, 1.0, 0.0);
+    xnormalize(xnormal(inv, nobj), n);
+    h.inside = xdot(n, h.eye) < 0.0;  // intersection.rs:48
+    if (h.inside) n = xneg(n);
+    h.normal = n;
+    h.reflectv = rd - n * 2.0 * xdot(rd, n);  // tuple.rs:121-123
+    h.over = h.point + n * kEpsD;
+    h.under = h.point - n * kEpsD;
+    return h;
+}
+
+// pattern.rs:58-96 at the over point (material.rs:127): object space, then pattern space.  Returns
+// whether colour a applies (Solid: always; Gradient: `frac` receives the blend factor instead).
+RT_HD bool xpattern_is_a(uint32_t pat_type, const double* prim_inv, const double* pat_inv, D3 over, double& frac) {
+    frac = 0.0;
+    if (pat_type == PAT_SOLID) return true;
+    const D3 pp = xpoint(pat_inv, xpoint(prim_inv, over));
+    switch (pat_type) {
+        case PAT_STRIPE: return xapprox(fmod(floor(pp.x), 2.0), 0.0);
+        case PAT_GRADIENT: frac = pp.x - floor(pp.x); return true;
+        case PAT_RING: return xapprox(fmod(floor(hypot(pp.x, pp.z)), 2.0), 0.0);
+        default: return xapprox(fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0), 0.0);
+    }
+}
+
+// world.rs:109-130: false under total internal reflection
+RT_HD bool xrefract(const XHit& h, double n1, double n2, D3& dir) {
+    const double n_ratio = n1 / n2;
+    const double cos_i = xdot(h.eye, h.normal);
+    const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);  // powi(x, 2) = x * x
+    if (sin2_t > 1.0) return false;
+    const double cos_t = sqrt(1.0 - sin2_t);
+    dir = h.normal * (n_ratio * cos_i - cos_t) - h.eye * n_ratio;
+    return true;
+}
+
+}  // namespace rtk

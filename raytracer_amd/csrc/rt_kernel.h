@@ -47,6 +47,7 @@
 
 #include <type_traits>
 
+#include "rt_exact.h"
 #include "rt_math.h"
 
 #ifndef RT_EXP
@@ -55,6 +56,10 @@
 // 64 no container pass | 128 no point-light shadow rays | 256 per-lane traversal | 512 Phong sums over one
 // cell | 1024 no shadow casting for area lights | 2048 no pyramid walk | 8192 no lane-local casting |
 // 16384 no shared Phong sums.  Every one of them renders a WRONG image except 2048, 8192 and 16384.
+#endif
+#ifndef RT_XEXP
+#define RT_XEXP 0  // timing experiments on the f64 chain (WRONG images): 1 no selection for spawning nodes | 2 no f64 hit
+// preparation | 4 no f64 pattern lookup | 8 no f64 refraction
 #endif
 #ifndef RT_BLOCK_THREADS
 // One tile (one wave) per workgroup: tiles differ in cost by an order of magnitude, and with four to a
@@ -90,12 +95,19 @@ struct KScene {
     const DMaterial* mats;
     const DPattern* pats;
     const DLight* lights;
+    // the caller's f64 tables (EXACT variants only; rt_exact.h): per record, per DExtra slot, per material, per pattern
+    const XPrim* xprims;
+    const XExtra* xextras;
+    const double* xior;
+    const XPattern* xpats;
     uint32_t n_items, n_lights;
     uint32_t has_gates, has_bvh;
+    uint32_t any_spawn;  // some material is reflective or transparent (no path has a second node otherwise)
 };
 struct KParams {
     KScene sc;
     DCamera cam;
+    XCamera cam64;  // EXACT variants only
     float* out;
     unsigned long long* counters;  // STATS variant only: kCounters x u64
     uint32_t* tile_rays;           // STATS variant only, may be null: rays cast per 8x8 tile, raster order of this call's rows
@@ -106,7 +118,7 @@ struct KParams {
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
-constexpr int kCounters = 9;  // primary, reflect, refract, shadow, shaded, cells, pattern, container, shadow rays CAST
+constexpr int kCounters = 10;  // primary, reflect, refract, shadow, shaded, cells, pattern, container, shadow rays CAST, nodes refined in f64
 
 // the builtin keeps the predicate as a lane mask (s_and with exec); __ballot() goes through a VGPR
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -322,7 +334,12 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
 constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) {
     return !AREA ? RT_MIN_BLOCKS_PLAIN : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
 }
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA>
+// EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
+// in f64 and the nodes that decide something are worked out again with the reference's formulas (rt_exact.h).
+struct Ray64 {
+    D3 o, d;
+};
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT>
 __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
 #ifdef RT_ORDER
     constexpr uint32_t kOrder = RT_ORDER;  // experiments
@@ -353,6 +370,26 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
 
     StackEntry stack[kStackCap];
     int sp = 0;
+    // The f64 copies of the path rays live in private memory, written when a node spawns them and read
+    // when a node is refined: [0] the child that continues in the lane, [1 + i] the ray of stack[i];
+    // `cur_slot` says where the current ray's copy is.  The camera ray (node 0) is never stored: it is
+    // worked out from the pixel when a refinement asks for it.  (Indexed dynamically, so the array never
+    // competes for registers.)
+    Ray64 r64[EXACT ? kStackCap + 1 : 1];
+    uint32_t cur_slot = 0;
+    auto cur64 = [&]() {
+        Ray64 r;
+        if (node == 0u) {
+            uint32_t l2 = threadIdx.x & 63u;
+            asm volatile("" : "+v"(l2));  // (recomputed like the final store's coordinates, not kept live)
+            uint32_t px, pyl, pgy;
+            pixel_of_lane(P, kOrder, wave, l2, px, pyl, pgy);
+            xcamera_ray(P.cam64, px, pgy, r.o, r.d);
+        } else {
+            r = r64[cur_slot];
+        }
+        return r;
+    };
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
@@ -361,7 +398,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
-                       c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0;
+                       c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0, c_refined = 0;
 
     while (wave_any(active)) {
         // ---------------------------------------------------------------- trace (world.rs:24-41)
@@ -369,22 +406,99 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if ((TREE && sc.has_bvh)) inv_d = inv_dir(cur.d);
-        auto trace_enter = [&](uint32_t, const DPrim& nd) { return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + tie_window(hit_t)); };
-        auto trace_visit = [&](uint32_t prim, const DPrim& p, auto self) {
-                intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int, float t, float u, float v) {
-                    // intersection.rs:105-120: smallest t > 0, world.objects order among approximately equal ones
-                    bool better = closer_hit(t, hit_t);
-                    if (!better && (TREE && sc.has_bvh) && hit_prim != kNoPrim && ties_hit(t, hit_t)) better = sc.order[prim] < sc.order[hit_prim];
-                    if (better && (TREE && sc.has_gates)) better = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);  // group.rs:107
-                    if (better) hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;
-                });
-                return true;
+        // EXACT: what the search cannot settle in FP32 — the winner's own test was a near thing, or another
+        // primitive lies within the window of the winner (or of t = 0) — is settled in f64 right after it.
+        bool hit_unsure = false, refined = false;
+        uint32_t alt_prim = kNoPrim, excl0 = kNoPrim, excl1 = kNoPrim;
+        float alt_t = INFINITY;
+        double t64 = 0.0, u64 = 0.0, v64 = 0.0;
+        // (The search and the f64 selection are written out as two calls each rather than as a loop: inside
+        // a loop the compiler no longer proves the walk's record index wave-uniform and the records come
+        // through vector loads — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
+        auto do_trace = [&](bool live) {
+            auto trace_enter = [&](uint32_t, const DPrim& nd) {
+                return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + (EXACT ? amb_window(hit_t) : tie_window(hit_t)));
             };
+            auto trace_visit = [&](uint32_t prim, const DPrim& p, auto self) {
+                    if (EXACT && (prim == excl0 || prim == excl1)) return true;
+                    // a candidate that is not the winner but within the window of it (the winner only ever gets
+                    // nearer, so a candidate outside the window now stays outside): keep the nearest one
+                    auto note_alt = [&](float t) {
+                        if (t <= hit_t + amb_window(hit_t) && t < alt_t && t > -amb_window(t) && prim != hit_prim && prim != cur.self &&
+                            (!(TREE && sc.has_gates) || gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d)))
+                            alt_prim = prim, alt_t = t;
+                    };
+                    auto emit = [&](int slot, float t, float u, float v) {
+                        // intersection.rs:105-120: smallest t > 0, world.objects order among approximately equal ones
+                        bool better = closer_hit(t, hit_t);
+                        if (!better && (TREE && sc.has_bvh) && hit_prim != kNoPrim && ties_hit(t, hit_t)) better = sc.order[prim] < sc.order[hit_prim];
+                        if (better && (TREE && sc.has_gates)) better = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);  // group.rs:107
+                        if (better) {
+                            if (EXACT && !(RT_XEXP & 16)) {
+                                // the old winner is the nearest loser so far, if it is within the new winner's window
+                                if (hit_prim != kNoPrim && hit_prim != prim && hit_t <= t + amb_window(t)) alt_prim = hit_prim, alt_t = hit_t;
+                                else if (alt_prim != kNoPrim && !(alt_t <= t + amb_window(t))) alt_prim = kNoPrim, alt_t = INFINITY;
+                                hit_unsure = (slot & kUnsure) != 0;
+                            }
+                            hit_t = t, hit_prim = prim, hit_u = u, hit_v = v;
+                        } else if (EXACT && !(RT_XEXP & 16)) {
+                            note_alt(t);
+                        }
+                    };
+                    if (EXACT && !(RT_XEXP & 16)) intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, emit, note_alt);
+                    else intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, emit);
+                    return true;
+                };
 #if RT_EXP & 256
-        if (TREE && wave_any(active && node != 0u)) traverse_lane(sc, cur.self, active, trace_enter, trace_visit);
-        else
+            if (TREE && wave_any(live && node != 0u)) traverse_lane(sc, cur.self, live, trace_enter, trace_visit);
+            else
 #endif
-            traverse<TREE>(sc, cur.self, active, trace_enter, trace_visit);
+                traverse<TREE>(sc, cur.self, live, trace_enter, trace_visit);
+        };
+        // Selection in f64 among what FP32 could not order, and for every node that spawns children.  Returns
+        // whether f64 found none of the candidates in front of the ray (then they are left out of a second search).
+        auto do_select = [&](bool live, bool may_retry) {
+            if (alt_prim != kNoPrim && hit_prim != kNoPrim && !(alt_t <= hit_t + amb_window(hit_t))) alt_prim = kNoPrim;  // too far behind to matter
+            bool spawns = false;
+            if (!(RT_XEXP & 1) && sc.any_spawn && live && hit_prim != kNoPrim) {
+                const DMaterial m = sc.mats[sc.recs[hit_prim].material];
+                spawns = P.max_depth > level_of(node) && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
+            }
+            bool retry = false;
+            if (live && (hit_unsure || alt_prim != kNoPrim || spawns)) {
+                XCandidates<EXOTIC ? 4 : 2> xc;
+                const Ray64 r = cur64();
+                const uint32_t a = hit_prim, b = alt_prim;  // entered in world.objects order
+                const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
+                const uint32_t first = a_first ? a : b, second = a_first ? b : a;
+                if (first != kNoPrim) {
+                    const DPrim p = sc.recs[first];
+                    xc.set(0, xintersect<EXOTIC>(p.type, sc.xprims[first].inv, sc.xextras[p.extra].f, r.o, r.d), first);
+                }
+                if (second != kNoPrim) {
+                    const DPrim p = sc.recs[second];
+                    xc.set(1, xintersect<EXOTIC>(p.type, sc.xprims[second].inv, sc.xextras[p.extra].f, r.o, r.d), second);
+                }
+                uint32_t pr = kNoPrim;
+                if (xc.hit(t64, pr, u64, v64)) {
+                    refined = true;
+                    hit_prim = pr, hit_t = static_cast<float>(t64), hit_u = static_cast<float>(u64), hit_v = static_cast<float>(v64);
+                } else {
+                    retry = may_retry;
+                    excl0 = a, excl1 = b;
+                    hit_prim = kNoPrim, hit_t = INFINITY, alt_prim = kNoPrim, alt_t = INFINITY, hit_unsure = false;
+                }
+            }
+            return retry;
+        };
+        do_trace(active);
+        if (EXACT) {
+            const bool retry = do_select(active, true);
+            if (wave_any(retry)) {  // rare: a grazing FP32 hit that f64 does not confirm
+                do_trace(retry);
+                do_select(retry, false);
+            }
+        }
         const bool has_hit = active && hit_prim != kNoPrim;
         const uint32_t depth = P.max_depth - level_of(node);  // remaining recursion depth of this node
 
@@ -395,7 +509,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         V3 pc = v3(0.0f, 0.0f, 0.0f);
         uint32_t mi = 0;
         float n1 = 1.0f, n2 = 1.0f;
-        bool need_n = false, hit_inside = false;
+        uint32_t n1_prim = kNoPrim, n2_prim = kNoPrim;  // EXACT: the records n1 / n2 came from
+        bool need_n = false, hit_inside = false, late = false;
         float m_ior = 1.0f;
         if (has_hit) {
             const DPrim p = sc.recs[hit_prim];
@@ -404,6 +519,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
             const HitInfo h = prepare_hit<EXOTIC>(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
             over = h.p + h.n * kEps, nrm = h.n, hq = h.q, hdq = h.dq, hit_inside = h.inside;
             pc = pattern_color(sc.pats[m.pattern], h.q + h.dq);  // pattern at over_point (material.rs:127)
+            // EXACT: a pattern lookup within FP32 reach of a boundary, or a local normal that was a near
+            // decision (the edge of a cube), is decided by the f64 hit of the same primitive
+            late = EXACT && !(RT_XEXP & 64) && !refined && (pattern_unsure(sc.pats[m.pattern], h.q + h.dq, h.eq) || h.edge);
             need_n = depth > 0u && m.transparency > 0.0f;
             m_ior = m.ior;
             // the reference looks the pattern up once per light (material.rs:127); Solid costs nothing
@@ -427,15 +545,61 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
                     Hits hh;
                     hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
                     bool any = false;
-                    intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot] = t, any = true; });
+                    intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot & 3] = t, any = true; });
                     if (any && (TREE && sc.has_gates)) any = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);
-                    if (any) cs.add(hh, prim == hit_prim, TREE ? sc.order[prim] : prim, p.ior, ord_hit, hit_t);
+                    if (any) cs.add(hh, prim == hit_prim, TREE ? sc.order[prim] : prim, p.ior, ord_hit, hit_t, prim);
                     return true;
                 });
             if (need_n) {
                 cs.finish(m_ior, n1, n2);
+                if (EXACT) cs.finish_prims(hit_prim, n1_prim, n2_prim);
                 if (STATS) c_container++;
             }
+        }
+        // ---------------------------------------------------------------- the f64 hit (rt_exact.h), refined nodes
+        // The reference's own hit point, normal, inside flag, pattern cell and child rays; the children go
+        // straight to private memory (r64[1] reflection, r64[2] refraction).
+        bool tir64 = false;
+        if (EXACT && !(RT_XEXP & 2) && has_hit && (refined || late)) {
+            const DPrim p = sc.recs[hit_prim];
+            const DMaterial m = sc.mats[mi];
+            const double* xinv = sc.xprims[hit_prim].inv;
+            const Ray64 r = cur64();
+            if (!refined) {  // (late: the same primitive's f64 hit; if f64 finds none the FP32 hit stands)
+                XCandidates<EXOTIC ? 4 : 2> xc;
+                xc.set(0, xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d), hit_prim);
+                uint32_t pr = kNoPrim;
+                refined = xc.hit(t64, pr, u64, v64);
+            }
+          if (refined) {
+            const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
+            over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
+            const DPattern pat = sc.pats[m.pattern];
+            if (!(RT_XEXP & 4) && pat.type != PAT_SOLID) {
+                double frac;
+                const bool is_a = xpattern_is_a(pat.type, xinv, sc.xpats[m.pattern].inv, xh.over, frac);
+                const V3 ca = v3(pat.a[0], pat.a[1], pat.a[2]), cb = v3(pat.b[0], pat.b[1], pat.b[2]);
+                pc = pat.type == PAT_GRADIENT ? ca + (cb - ca) * static_cast<float>(frac) : (is_a ? ca : cb);
+            }
+            // the children's f64 rays go to where the children phase below expects them: the one that
+            // continues in the lane to r64[0], a refraction that waits on the stack to r64[1 + sp]
+            const bool refl = depth > 0u && !(fabsf(m.reflectivity) <= kEps);
+            bool refr = depth > 0u && !(fabsf(m.transparency) <= kEps);
+            D3 rd = d3(0.0, 0.0, 0.0);
+            if ((RT_XEXP & 8) && refr) rd = to_d3(v3(0.1f, 0.2f, 0.3f));
+            if (!(RT_XEXP & 8) && refr) {  // world.rs:109-130 with the f64 indices of the records the container pass named
+                const double x1 = n1_prim == kNoPrim ? 1.0 : sc.xior[sc.recs[n1_prim].material];
+                const double x2 = n2_prim == kNoPrim ? 1.0 : sc.xior[sc.recs[n2_prim].material];
+                tir64 = !xrefract(xh, x1, x2, rd);
+                refr = !tir64;
+            }
+            if (refr) {
+                Ray64& slot = r64[(refl && sp < kStackCap) ? 1 + sp : 0];
+                slot.o = xh.under, slot.d = rd;
+            }
+            if (refl) r64[0].o = xh.over, r64[0].d = xh.reflectv;
+            if (STATS) c_refined++;
+          }
         }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
@@ -836,27 +1000,39 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         bool want_refr = has_hit && depth > 0u && !(fabsf(m_transparency) <= kEps);
         const bool use_schlick = has_hit && (m_reflectivity * m_transparency) > 0.0f;
         V3 rdir = v3(0.0f, 0.0f, 0.0f);
-        if (want_refr && !refract_dir(eye, nrm, n1, n2, rdir)) want_refr = false;  // total internal reflection
+        const bool chain = EXACT && refined && !(RT_XEXP & 2);  // the children's f64 rays wait in r64[]
+        if (want_refr && (chain ? tir64 : !refract_dir(eye, nrm, n1, n2, rdir))) want_refr = false;  // total internal reflection
         const float fr = use_schlick ? schlick(eye, nrm, n1, n2) : 0.0f;
         // The reference adds reflected + refracted colour once PER LIGHT (world.rs:44-69): the
         // recursion is traced once here and weighted by the number of lights.
         const float k_refl = nlights * m_reflectivity * (use_schlick ? fr : 1.0f);
         const float k_refr = nlights * m_transparency * (use_schlick ? (1.0f - fr) : 1.0f);
-        const V3 under = over - nrm * (2.0f * kEps);  // point - n*eps (intersection.rs:53)
+        V3 under = over - nrm * (2.0f * kEps);  // point - n*eps (intersection.rs:53)
+        const bool push = has_hit && want_refl && want_refr && sp < kStackCap;
+        if (EXACT && !(RT_XEXP & 32) && has_hit && want_refr) {
+            // the refraction ray's f64 copy: written by the refined node above, else (no f64 hit) the chain
+            // restarts from the FP32 ray
+            Ray64& slot = r64[push ? 1 + sp : 0];
+            if (chain) under = to_v3(slot.o), rdir = to_v3(slot.d);
+            else slot.o = to_d3(under), slot.d = to_d3(rdir);
+        }
 
-        if (has_hit && want_refl && want_refr) {
-            if (sp < kStackCap) {
-                StackEntry e;
-                e.o = under, e.d = rdir, e.w = w * k_refr, e.q = hq, e.dq = neg(hdq);
-                e.self = hit_prim, e.node = 2u * node + 2u;
-                stack[sp++] = e;
-                if (STATS) c_refract++;
-            }
+        if (push) {
+            StackEntry e;
+            e.o = under, e.d = rdir, e.w = w * k_refr, e.q = hq, e.dq = neg(hdq);
+            e.self = hit_prim, e.node = 2u * node + 2u;
+            stack[sp++] = e;
+            if (STATS) c_refract++;
         }
         if (has_hit && want_refl) {
             cur.o = over;
             const V3 din = neg(eye);                     // the incoming direction, back from its parked negation
             cur.d = din - nrm * (2.0f * dot(din, nrm));  // tuple.rs:121-123
+            if (EXACT && !(RT_XEXP & 32)) {
+                if (chain) cur.d = to_v3(r64[0].d);
+                else r64[0].o = to_d3(cur.o), r64[0].d = to_d3(cur.d);
+                cur_slot = 0;
+            }
             cur.self = hit_prim, cur.q = hq, cur.dq = hdq;
             w = w * k_refl;
             node = 2u * node + 1u;
@@ -864,6 +1040,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         } else if (has_hit && want_refr) {
             cur.o = under;
             cur.d = rdir;
+            if (EXACT) cur_slot = 0;
             cur.self = hit_prim, cur.q = hq, cur.dq = neg(hdq);
             w = w * k_refr;
             node = 2u * node + 2u;
@@ -872,6 +1049,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
             if (sp > 0) {
                 const StackEntry e = stack[--sp];
                 cur.o = e.o, cur.d = e.d, cur.self = e.self, cur.q = e.q, cur.dq = e.dq;
+                if (EXACT) cur_slot = 1u + static_cast<uint32_t>(sp);
                 w = e.w;
                 node = e.node;
             } else {
@@ -892,7 +1070,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         }
     }
     if (STATS) {
-        unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast};
+        unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
         unsigned long long cast_rays = 0;  // primary + reflection + refraction + shadow rays really traced
         for (int k = 0; k < kCounters; ++k) {
             unsigned long long s = v[k];

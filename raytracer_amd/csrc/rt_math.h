@@ -168,6 +168,9 @@ RT_HD float min_by3(float a, float b, float c) {
 // 1e-5 * max(1, t/4): the reference's own window wherever FP32 can resolve it, wider only where it
 // cannot.
 RT_HD float tie_window(float t) { return kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
+// Two candidates closer than this (or a candidate this close to t = 0) are more than FP32 can order
+// against the reference's 1e-5 tie rule: the exact chain (rt_exact.h) settles them in f64.
+RT_HD float amb_window(float t) { return 4.0f * kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
 RT_HD bool closer_hit(float t, float best) { return t > 0.0f && t < best - tie_window(t); }  // best may be +inf
 // Candidates do not always arrive in world.objects order (the device walks its own hierarchy): an
 // approximately equal t is a TIE, which the caller resolves by the primitives' order keys.
@@ -228,21 +231,38 @@ RT_HD bool on_surface_roots(float a, float h, float c, float& t0, float& t1) {
 }
 
 // sphere.rs:38-72.  a = d.d, h = d.o (= b/2), c = o.o - 1.  Always two roots when it hits.
-template <class Emit>
-RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit) {
+// Candidates the FP32 tests cannot settle (the exact chain, rt_exact.h, works them out in f64): a hit
+// whose own test was a near thing is emitted with kUnsure added to its slot; a MISS that was a near
+// thing is reported to `soft(t)` with the parameter where the hit would be.  Thresholds are in object
+// units and generous (FP32 error of an object-space ray position is ~1e-7 |translation| / scale):
+// the band of rays they catch is ~1e-4 of a shape's projected area.
+constexpr int kUnsure = 8;
+constexpr float kGraze = 1e-4f;
+struct NoSoft {
+    RT_HD void operator()(float) const {}
+};
+template <class Emit, class Soft>
+RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit, Soft&& soft) {
     float a = dot(d, d);
     float t0, t1;
+    int unsure = 0;
     if (self) {
         // |q| == 1 exactly by construction, so c = |q + dq|^2 - 1 = 2 q.dq + dq.dq without cancellation
         if (!on_surface_roots(a, dot(d, q + dq), fmaf(2.0f, dot(q, dq), dot(dq, dq)), t0, t1)) return;
     } else {
         float tc, half;
         V3 l;
-        if (!sphere_foot(o, d, a, tc, l, half)) return;  // discriminant < 0  (sphere.rs:51)
+        const bool ok = sphere_foot(o, d, a, tc, l, half);  // discriminant < 0  (sphere.rs:51)
+        const float m = 1.0f - dot(l, l);
+        if (!ok) {
+            if (m > -kGraze) soft(tc);
+            return;
+        }
+        unsure = m < kGraze ? kUnsure : 0;
         t0 = tc - half, t1 = tc + half;
     }
-    emit(0, t0, 0.0f, 0.0f);
-    emit(1, t1, 0.0f, 0.0f);
+    emit(0 | unsure, t0, 0.0f, 0.0f);
+    emit(1 | unsure, t1, 0.0f, 0.0f);
 }
 
 // cube.rs:39-122 (the same slab code serves Group boxes: bounding_box.rs:81-84).
@@ -264,8 +284,8 @@ RT_HD void isect_box(V3 num_lo, V3 num_hi, V3 d, float& tmin, float& tmax) {
     tmin = max_by3(x0, y0, z0);
     tmax = min_by3(x1, y1, z1);
 }
-template <class Emit>
-RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit) {
+template <class Emit, class Soft>
+RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit, Soft&& soft) {
     V3 lo, hi;
     if (self) {  // the snapped coordinate of q is exactly +-1, so (bound - q) is exactly 0 or +-2
         lo = (v3(-1.0f, -1.0f, -1.0f) - q) - dq;
@@ -276,9 +296,14 @@ RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit) {
     }
     float tmin, tmax;
     isect_box(lo, hi, d, tmin, tmax);
-    if (tmin > tmax) return;  // cube.rs:104
-    emit(0, tmin, 0.0f, 0.0f);
-    emit(1, tmax, 0.0f, 0.0f);
+    const float room = kGraze * fmaxf(1.0f, fabsf(tmax));  // the ray clips an edge of the cube
+    if (tmin > tmax) {  // cube.rs:104
+        if (tmin - tmax <= room) soft(tmax);
+        return;
+    }
+    const int unsure = (tmax - tmin <= room) ? kUnsure : 0;
+    emit(0 | unsure, tmin, 0.0f, 0.0f);
+    emit(1 | unsure, tmax, 0.0f, 0.0f);
 }
 
 // cylinder.rs:126-225
@@ -327,27 +352,34 @@ RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float 
 }
 
 // triangle.rs:104-133 (Moller-Trumbore); e = {v0, e0, e1}
-template <class Emit>
-RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Emit&& emit) {
+template <class Emit, class Soft>
+RT_HD void isect_triangle(V3 o, V3 d, V3 v0, V3 e0, V3 e1, Emit&& emit, Soft&& soft) {
     V3 dir_cross_e1 = cross(d, e1);
     float det = dot(e0, dir_cross_e1);
     if (fabsf(det) <= kEps) return;
     float f = rcp_f(det);
     V3 p0 = o - v0;
     float u = f * dot(p0, dir_cross_e1);
-    if (!(u >= 0.0f && u <= 1.0f)) return;
+    if (!(u >= -kGraze && u <= 1.0f + kGraze)) return;
     V3 oxe0 = cross(p0, e0);
     float v = f * dot(d, oxe0);
-    if (v < 0.0f || (u + v) > 1.0f) return;
-    emit(0, f * dot(e1, oxe0), u, v);
+    if (v < -kGraze || (u + v) > 1.0f + kGraze) return;
+    const float t = f * dot(e1, oxe0);
+    const bool hit = (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || (u + v) > 1.0f);  // triangle.rs:117-125
+    if (!hit) {  // within the margin of an edge: the neighbour across the edge may or may not take the ray
+        soft(t);
+        return;
+    }
+    const bool edge = u < kGraze || v < kGraze || (u + v) > 1.0f - kGraze;
+    emit(edge ? kUnsure : 0, t, u, v);
 }
 
 // Dispatch: world ray -> object space (shape.rs:79-81, ray.rs:17-22) -> primitive test.
 // EXOTIC = false compiles the cylinder / triangle code out: a kernel instantiated that way (for
 // scenes without such primitives — rt_scene_create knows) is 6-20 % faster on the other shapes
 // because the register allocation and the instruction cache are no longer sized by the rare paths.
-template <bool EXOTIC = true, class Emit>
-RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Emit&& emit) {
+template <bool EXOTIC = true, class Emit, class Soft>
+RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Emit&& emit, Soft&& soft) {
     switch (p.type) {
         case PRIM_PLANE: {  // plane.rs:39-51 — only the y row of the inverse is needed
             float oy = self ? ray.dq.y : fmaf(p.inv[4], ray.o.x, fmaf(p.inv[5], ray.o.y, fmaf(p.inv[6], ray.o.z, p.inv[7])));
@@ -357,12 +389,12 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
         }
         case PRIM_SPHERE: {
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
-            isect_sphere(o, d, self, ray.q, ray.dq, emit);
+            isect_sphere(o, d, self, ray.q, ray.dq, emit, soft);
             break;
         }
         case PRIM_CUBE: {
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
-            isect_cube(o, d, self, ray.q, ray.dq, emit);
+            isect_cube(o, d, self, ray.q, ray.dq, emit, soft);
             break;
         }
         case PRIM_CYLINDER: {
@@ -377,10 +409,15 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             if (self) o = ray.q + ray.dq;
             const float* e = extras[p.extra].f;
-            isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), emit);
+            isect_triangle(o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]), emit, soft);
             break;
         }
     }
+}
+// Without the near-miss reports: `emit` still receives kUnsure in the slot and must mask it (slot & 3).
+template <bool EXOTIC = true, class Emit>
+RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, Emit&& emit) {
+    intersect_prim<EXOTIC>(p, extras, ray, self, emit, NoSoft{});
 }
 
 // Shadow rays only ask "is there an intersection with 0 < t < dist" (world.rs:73-92: the nearest
@@ -700,9 +737,10 @@ RT_HD int shaft_side_of_surface(const Shaft& s, V3 n, const DLight& l) {
 struct ContainerScan {
     float best_t = -INFINITY, best_ior = 1.0f, hit_last = -INFINITY;
     bool have_best = false, hit_in = false;
+    uint32_t best_prim = kNoPrim;  // the record best_ior came from (the exact chain reads its f64 index)
 
     // ord / ord_hit: world.objects positions of this primitive and of the hit one
-    RT_HD void add(const Hits& h, bool is_hit_prim, uint32_t ord, float ior, uint32_t ord_hit, float t_hit) {
+    RT_HD void add(const Hits& h, bool is_hit_prim, uint32_t ord, float ior, uint32_t ord_hit, float t_hit, uint32_t prim = kNoPrim) {
         int skipk = -1;  // the hit itself = the hit primitive's intersection closest to t_hit
         float bd = INFINITY;
         for (int k = 0; k < 4; ++k)
@@ -713,7 +751,7 @@ struct ContainerScan {
             if (k != skipk && h.t[k] == h.t[k] && precedes_hit(h.t[k], t_hit, ord, ord_hit)) ++cnt, last = fmaxf(last, h.t[k]);
         if (cnt & 1) {
             if (is_hit_prim) hit_in = true, hit_last = last;
-            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = ior;
+            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = ior, best_prim = prim;
         }
     }
     RT_HD void finish(float hit_ior, float& n1, float& n2) const {
@@ -724,6 +762,17 @@ struct ContainerScan {
         } else {
             n1 = excl;
             n2 = hit_ior;
+        }
+    }
+    // The same answer as record indices: kNoPrim = outside everything (index 1.0), `hit_prim` = the hit one.
+    RT_HD void finish_prims(uint32_t hit_prim, uint32_t& p1, uint32_t& p2) const {
+        const uint32_t excl = have_best ? best_prim : kNoPrim;
+        if (hit_in) {
+            p1 = (!have_best || hit_last > best_t) ? hit_prim : best_prim;
+            p2 = excl;
+        } else {
+            p1 = excl;
+            p2 = hit_prim;
         }
     }
 };
@@ -737,6 +786,8 @@ struct HitInfo {
     V3 q;        // snapped object-space hit point
     V3 dq;       // object-space offset of over_point: eps * inv_linear * n   (under_point: -dq)
     bool inside;
+    V3 eq;       // bound on the FP32 error of the object-space hit point, per axis (pattern_unsure)
+    bool edge;   // the local normal was a near decision: the edge of a cube, the rim of a capped cylinder
 };
 
 template <bool EXOTIC = true>
@@ -746,6 +797,11 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
     if (self) o = ray.q + ray.dq;
     V3 q = madd(d, t, o);
     V3 nobj = v3(0.0f, 1.0f, 0.0f);
+    {  // (a coordinate the snap below makes exact carries no error: the height over a plane, a cube's face)
+        const float e = 3e-7f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(t) * (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) + 1.0f);
+        h.eq = v3(e, e, e);
+    }
+    h.edge = false;
     switch (p.type) {
         case PRIM_SPHERE: {  // sphere.rs:74-76 — hit point from the perpendicular foot, snapped onto the unit sphere
             float tc, half;
@@ -757,19 +813,24 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
         }
         case PRIM_PLANE:  // plane.rs:53-55
             q.y = 0.0f;
+            h.eq.y = 0.0f;
             nobj = v3(0.0f, 1.0f, 0.0f);
             break;
         case PRIM_CUBE: {  // cube.rs:125-141: exact max, then approx tie order x, y, z
             float ax = fabsf(q.x), ay = fabsf(q.y), az = fabsf(q.z);
             float mc = fmaxf(ax, fmaxf(ay, az));
+            h.edge = (ax > mc - kGraze ? 1 : 0) + (ay > mc - kGraze ? 1 : 0) + (az > mc - kGraze ? 1 : 0) >= 2;
             if (approx(mc, ax)) {
                 q.x = copysignf(1.0f, q.x);
+                h.eq.x = 0.0f;
                 nobj = v3(q.x, 0.0f, 0.0f);
             } else if (approx(mc, ay)) {
                 q.y = copysignf(1.0f, q.y);
+                h.eq.y = 0.0f;
                 nobj = v3(0.0f, q.y, 0.0f);
             } else {
                 q.z = copysignf(1.0f, q.z);
+                h.eq.z = 0.0f;
                 nobj = v3(0.0f, 0.0f, q.z);
             }
             break;
@@ -779,6 +840,7 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             const float* e = extras[p.extra].f;
             float dist = fmaf(q.x, q.x, q.z * q.z);
             float top = e[1] - kEps, bot = e[0] + kEps;
+            h.edge = dist > 0.99f && (fabsf(q.y - e[1]) < kGraze || fabsf(q.y - e[0]) < kGraze);
             if (dist < 1.0f && (approx(q.y, top) || q.y > top)) {
                 q.y = e[1];
                 nobj = v3(0.0f, 1.0f, 0.0f);
@@ -840,6 +902,32 @@ RT_HD V3 pattern_color(const DPattern& pat, V3 obj_point) {
         case PAT_GRADIENT: return a + (b - a) * (pp.x - floorf(pp.x));
         case PAT_RING: return is_even(floorf(sqrtf(fmaf(pp.x, pp.x, pp.z * pp.z)))) ? a : b;
         default: return is_even(floorf(pp.x) + floorf(pp.y) + floorf(pp.z)) ? a : b;
+    }
+}
+
+// Does the pattern decision at obj_point lie within FP32 reach of a boundary (then the exact chain
+// decides it in f64)?  e_q bounds the error of obj_point itself; the pattern-space coordinates add the
+// rounding of their own sums, relative to the size of the terms (so the height 1e-5 of an over point
+// above its own plane, a sum of one small term, counts as decided).
+RT_HD bool pattern_unsure(const DPattern& pat, V3 p, V3 e_q) {
+    if (pat.type == PAT_SOLID) return false;
+    float c[3], room[3];
+    for (int k = 0; k < 3; ++k) {
+        const float* m = pat.inv + 4 * k;
+        c[k] = fmaf(m[0], p.x, fmaf(m[1], p.y, fmaf(m[2], p.z, m[3])));
+        const float lin = fabsf(m[0]) * e_q.x + fabsf(m[1]) * e_q.y + fabsf(m[2]) * e_q.z;
+        const float mag = fabsf(m[0] * p.x) + fabsf(m[1] * p.y) + fabsf(m[2] * p.z) + fabsf(m[3]);
+        room[k] = fmaf(4e-7f, mag, lin);
+    }
+    auto near = [](float x, float r) {
+        const float f = x - floorf(x);
+        return !(fminf(f, 1.0f - f) > r);  // NaN counts as near
+    };
+    switch (pat.type) {
+        case PAT_STRIPE:
+        case PAT_GRADIENT: return near(c[0], room[0]);
+        case PAT_RING: return near(sqrtf(fmaf(c[0], c[0], c[2] * c[2])), room[0] + room[2]);
+        default: return near(c[0], room[0]) || near(c[1], room[1]) || near(c[2], room[2]);
     }
 }
 

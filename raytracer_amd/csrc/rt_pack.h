@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "rt_exact.h"
 #include "rt_math.h"
 
 namespace rtk {
@@ -36,9 +37,17 @@ struct PackedScene {
     std::vector<DMaterial> mats;
     std::vector<DPattern> pats;
     std::vector<DLight> lights;
+    // the caller's f64 tables for the exact chain (rt_exact.h), laid out like their FP32 twins: per stream
+    // record, per DExtra slot, per material, per pattern.  Empty when the caller did not provide them.
+    std::vector<XPrim> xprims;
+    std::vector<XExtra> xextras;
+    std::vector<double> xior;
+    std::vector<XPattern> xpats;
+    bool has_f64 = false;
     uint32_t n_items = 0, n_lights = 0;  // real counts (the vectors are padded to be non-empty)
     uint32_t max_cells = 1;              // largest usteps*vsteps over the lights
     bool has_gates = false, has_bvh = false, exotic = false, has_area = false;
+    bool any_spawn = false;  // some material is reflective or transparent
 };
 
 constexpr uint32_t kFlatLimit = 8;  // at most this many primitives and no Groups: no hierarchy
@@ -298,6 +307,9 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     }
 
     out = PackedScene{};
+    const int n64 = (d->prim_inv64 ? 1 : 0) + (d->prim_param64 ? 1 : 0) + (d->mat_ior64 ? 1 : 0) + (d->pat_inv64 ? 1 : 0);
+    if (n64 != 0 && n64 != 4) return bad("the f64 tables (prim_inv64, prim_param64, mat_ior64, pat_inv64) come all four or not at all");
+    out.has_f64 = n64 == 4;
     for (uint32_t i = 0; i < d->n_patterns; ++i) {
         if (d->pat_type[i] > RT_PAT_CHECKER) {
             err = "unknown pattern tag";
@@ -309,11 +321,18 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         std::memcpy(p.b, d->pat_color_b + 3 * i, sizeof(p.b));
         p.type = d->pat_type[i];
         out.pats.push_back(p);
+        if (out.has_f64) {
+            XPattern xp{};
+            std::memcpy(xp.inv, d->pat_inv64 + 12 * i, sizeof(xp.inv));
+            out.xpats.push_back(xp);
+        }
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         if (d->mat_pattern[i] >= d->n_patterns) return bad("material pattern index out of range");
         const float* m = d->mat_param + 8 * i;
         out.mats.push_back(DMaterial{m[0], m[1], m[2], m[3], m[4], m[5], m[6], d->mat_pattern[i]});
+        out.any_spawn |= !(std::fabs(m[5]) <= kEps) || !(std::fabs(m[6]) <= kEps);
+        if (out.has_f64) out.xior.push_back(d->mat_ior64[i]);
     }
     std::vector<DPrim> prims;  // by primitive index
     for (uint32_t i = 0; i < d->n_prims; ++i) {
@@ -334,10 +353,16 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
             std::memcpy(e.f, d->prim_param + 24 * i, 24 * sizeof(float));
             p.extra = static_cast<uint32_t>(out.extras.size());
             out.extras.push_back(e);
+            if (out.has_f64) {
+                XExtra xe{};
+                std::memcpy(xe.f, d->prim_param64 + 24 * i, sizeof(xe.f));
+                out.xextras.push_back(xe);
+            }
         }
         prims.push_back(p);
     }
     if (out.extras.empty()) out.extras.push_back(DExtra{});  // never hand a null table to the kernel
+    if (out.xextras.empty()) out.xextras.push_back(XExtra{});
 
     // The caller's item tree: pre-order with forward skip links.  i < next <= n_items and proper
     // nesting are checked; Groups become gates, primitives remember their innermost Group.
@@ -415,6 +440,17 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     if (out.recs.empty()) out.recs.push_back(DPrim{}), out.order.push_back(0), out.gate.push_back(kNoGate);
     for (const DPrim& r : out.recs)
         out.bound.push_back(r.type == REC_NODE ? node_ball(r) : prim_world_ball(r.type, r.inv, out.extras[r.extra].f));
+    if (out.has_f64) {  // record i of the stream is the primitive of item order[i]
+        out.xprims.resize(out.recs.size());
+        for (size_t i = 0; i < out.n_items; ++i) {
+            if (out.recs[i].type == REC_NODE) continue;
+            const uint32_t ref = d->item_ref[out.order[i]];
+            std::memcpy(out.xprims[i].inv, d->prim_inv64 + 12 * static_cast<size_t>(ref), sizeof(out.xprims[i].inv));
+        }
+    }
+    if (out.xprims.empty()) out.xprims.push_back(XPrim{});
+    if (out.xpats.empty()) out.xpats.push_back(XPattern{});
+    if (out.xior.empty()) out.xior.push_back(1.0);
 
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         if (d->light_type[i] > RT_LIGHT_AREA) {
@@ -445,6 +481,12 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     return RT_OK;
 }
 
+inline XCamera pack_camera64(const rt_camera_desc& c) {
+    XCamera x{};
+    x.pixel_size = c.pixel_size64, x.half_width = c.half_width64, x.half_height = c.half_height64;
+    std::memcpy(x.inv, c.inv64, sizeof(x.inv));
+    return x;
+}
 inline DCamera pack_camera(const rt_camera_desc& c) {
     DCamera d{};
     d.pixel_size = c.pixel_size, d.half_width = c.half_width, d.half_height = c.half_height;

@@ -88,6 +88,10 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     results = []
+    cj = os.path.join(a.out, "census.json")
+    if os.path.exists(cj):  # earlier calls into the same directory: keep their rows
+        with open(cj) as f:
+            results = json.load(f)
     for name in (a.names or list(FULL)):
         w, h = FULL[name]
         w, h = max(8, int(w * a.scale)), max(8, int(h * a.scale))
@@ -95,7 +99,7 @@ def main():
         for jitter, seed in modes:
             bands = a.rows_4k if (h >= 2160 and a.rows_4k) else 0
             r = census(name, w, h, jitter, seed, a.threads, bands, a.out)
-            results.append(r)
+            results = [x for x in results if (x["scene"], x["jitter"]) != (r["scene"], r["jitter"])] + [r]
             print(f"{name:42s} {w}x{h} {r['jitter']:7s} bad {r['bad_pixels']:6d} / {r['pixels_compared']} = {r['bad_frac']:.2e} "
                   f"max {r['max_abs']:.2e} p99.9 {r['p999_abs']:.1e} | PNG bytes >1: {r['png_bytes_off_by_more_than_1']} "
                   f"(=1: {r['png_bytes_off_by_1']}) | gpu {r['gpu_kernel_ms']:.2f} ms oracle {r['oracle_seconds']:.1f} s", flush=True)

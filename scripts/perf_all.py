@@ -55,13 +55,21 @@ def main():
             _, st = sc.render(ex.camera_desc, opt)
             if k:
                 msj.append(st.kernel_ms)
+        opt32 = RtOptions()
+        opt32.jitter_mode, opt32.seed, opt32.flags = 1, 0, 2  # RT_FLAG_F32_ONLY: the same frame without the f64 chain
+        ms32 = []
+        for k in range(a.reps + 1):
+            _, st = sc.render(ex.camera_desc, opt32)
+            if k:
+                ms32.append(st.kernel_ms)
         _, st = sc.render(ex.camera_desc, opt, stats=True)
         d = st.as_dict()
         rays = st.total_rays()
         n_lights = int(ex.scene_desc.contents.n_lights)
         has_nodes = int(ex.scene_desc.contents.n_nodes) > 0
         flops = None if has_nodes else flopmodel.frame_flops(d, n_lights, flopmodel.flat_ray_cost(ex.scene_desc))
-        line = (f"{name:42s} {w}x{h} centre: best {min(ms):8.3f} ms mean {np.mean(ms):8.3f} | counter: best {min(msj):8.3f} ms "
+        line = (f"{name:42s} {w}x{h} centre: best {min(ms):8.3f} ms mean {np.mean(ms):8.3f} | counter: best {min(msj):8.3f} ms (FP32 only {min(ms32):7.3f}, "
+                f"f64 nodes {d.get('exact_nodes', 0) / 1e6:.2f} M) "
                 f"| rays {rays / 1e6:9.2f} M -> {rays / min(msj) / 1e3:9.1f} Mrays/s")
         if flops:
             line += f" | {flops / min(msj) / 1e9:6.2f} TFLOP/s ({100 * flops / min(msj) / 1e9 / flopmodel.PEAK_FP32_TFLOPS:4.1f} %)"

@@ -24,12 +24,18 @@ namespace {
 struct Sim {
     PackedScene ps;
     DCamera cam;
+    XCamera cam64;
+    bool exact = false;  // the f64 chain of rt_exact.h is on (scene and camera carry f64 tables)
     uint32_t max_depth, jitter_mode, seed;
 };
 
 struct Closest {
     uint32_t prim;
     float t, u, v;
+    // what the exact chain needs to know about the search (rt_kernel.h keeps the same three values):
+    bool unsure = false;         // the winning test was a near thing
+    uint32_t alt = kNoPrim;      // another primitive FP32 cannot tell from the winner (or from a hit at all)
+    float alt_t = INFINITY;
 };
 
 // visit(i, record) -> keep going?   Records are walked in stream order; a node of the device's
@@ -53,16 +59,32 @@ bool gated_in(const Sim& s, uint32_t prim, const Ray& ray) {
     return !s.ps.has_gates || gates_pass(s.ps.gates.data(), s.ps.gate[prim], ray.o, ray.d);
 }
 
-Closest closest_hit(const Sim& s, const Ray& ray) {
+Closest closest_hit(const Sim& s, const Ray& ray, uint32_t excl0 = kNoPrim, uint32_t excl1 = kNoPrim) {
     Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
-    traverse(s, ray, 0.0f, [&] { return c.t + tie_window(c.t); }, [&](uint32_t prim, const DPrim& p) {
-        intersect_prim(p, s.ps.extras.data(), ray, prim == ray.self, [&](int, float t, float u, float v) {
+    auto note_alt = [&](uint32_t prim, float t) {  // a candidate that is not the winner: keep the nearest one
+        // (the primitive the ray starts on: its near roots are exact by construction, rt_math.h "self")
+        if (t <= c.t + amb_window(c.t) && t < c.alt_t && t > -amb_window(t) && prim != c.prim && prim != ray.self && gated_in(s, prim, ray))
+            c.alt = prim, c.alt_t = t;
+    };
+    traverse(s, ray, 0.0f, [&] { return c.t + (s.exact ? amb_window(c.t) : tie_window(c.t)); }, [&](uint32_t prim, const DPrim& p) {
+        if (prim == excl0 || prim == excl1) return true;
+        intersect_prim(p, s.ps.extras.data(), ray, prim == ray.self, [&](int slot, float t, float u, float v) {
             bool better = closer_hit(t, c.t);
             if (!better && c.prim != kNoPrim && ties_hit(t, c.t)) better = s.ps.order[prim] < s.ps.order[c.prim];
-            if (better && gated_in(s, prim, ray)) c = Closest{prim, t, u, v};
-        });
+            if (better) {
+                if (!gated_in(s, prim, ray)) return;  // group.rs:107: the ray does not see this primitive
+                const Closest old = c;
+                c.prim = prim, c.t = t, c.u = u, c.v = v, c.unsure = (slot & kUnsure) != 0;
+                // the old winner is the nearest loser so far, if it is within the new winner's window
+                if (old.prim != kNoPrim && old.prim != prim && old.t <= t + amb_window(t)) c.alt = old.prim, c.alt_t = old.t;
+                else if (c.alt != kNoPrim && !(c.alt_t <= t + amb_window(t))) c.alt = kNoPrim, c.alt_t = INFINITY;
+            } else if (s.exact) {
+                note_alt(prim, t);
+            }
+        }, [&](float t) { if (s.exact) note_alt(prim, t); });
         return true;
     });
+    if (c.alt != kNoPrim && c.prim != kNoPrim && !(c.alt_t <= c.t + amb_window(c.t))) c.alt = kNoPrim;  // too far behind to matter
     return c;
 }
 
@@ -84,7 +106,8 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
 // intersection.rs:71-103 without the sorted list: a primitive is a "container" at the hit iff an
 // odd number of its intersections precede the hit; `visited.last()` is the container whose last
 // crossing before the hit has the largest t.
-void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2) {
+void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2, uint32_t& n1_prim,
+                uint32_t& n2_prim) {
     ContainerScan cs;
     const V3 hp = madd(ray.d, t_hit, ray.o);
     const float hm = container_margin(t_hit, hp);
@@ -100,10 +123,11 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
         Hits h;
         h.t[0] = h.t[1] = h.t[2] = h.t[3] = RT_NOHIT;
         bool any = false;
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot] = t, any = true; });
-        if (any && gated_in(s, prim, ray)) cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit);
+        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot & 3] = t, any = true; });
+        if (any && gated_in(s, prim, ray)) cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit, prim);
     }
     cs.finish(hit_ior, n1, n2);
+    cs.finish_prims(hit_prim, n1_prim, n2_prim);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,6 +259,7 @@ void audit_shaft(const Sim& s, const DLight& l, uint32_t li, uint32_t pixel_key,
 
 struct PathNode {
     Ray ray;
+    D3 o64, d64;  // the same ray in f64 (the exact chain, rt_exact.h)
     V3 w;
     uint32_t depth, node;
 };
@@ -256,6 +281,10 @@ Closest closest_hit_fixed_window(const Sim& s, const Ray& ray) {
     return c;
 }
 
+// Statistics of the exact chain (hostsim_exact_stats): path nodes, nodes refined in f64, by reason.
+std::atomic<uint64_t> g_x_nodes{0}, g_x_refined{0}, g_x_children{0}, g_x_pattern{0}, g_x_amb{0}, g_x_edge{0}, g_x_changed{0},
+    g_x_retry{0};
+
 V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
     V3 acc = v3(0, 0, 0);
     if (s.ps.n_lights == 0) return acc;  // world.rs:44: fold over no lights == BLACK
@@ -264,22 +293,88 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
     int sp = 0;
     PathNode cur;
     camera_ray(s.cam, x, y, cur.ray.o, cur.ray.d);
+    cur.o64 = d3(0, 0, 0), cur.d64 = d3(0, 0, 0);
+    if (s.exact) xcamera_ray(s.cam64, x, y, cur.o64, cur.d64);
     cur.ray.self = kNoPrim, cur.ray.q = v3(0, 0, 0), cur.ray.dq = v3(0, 0, 0);
     cur.w = v3(1, 1, 1), cur.depth = s.max_depth, cur.node = 0;
     const float nl = static_cast<float>(s.ps.n_lights);
+    const DExtra* ex = s.ps.extras.data();
     for (;;) {
         bool alive = false;
+        // ---- nearest hit: FP32 search; the exact chain settles what FP32 cannot and refines what matters
         Closest c = closest_hit(s, cur.ray);
         if (g_tie_audit && c.prim != kNoPrim) {
             const Closest f = closest_hit_fixed_window(s, cur.ray);
             g_tie_hits += 1, g_tie_differs += (f.prim != c.prim) ? 1u : 0u, g_tie_wide_used += (tie_window(c.t) > kEps) ? 1u : 0u;
         }
-        if (c.prim != kNoPrim) {
-            const DPrim& p = s.ps.recs[c.prim];
+        bool refined = false;
+        XHit xh{};
+        double t64 = 0.0, u64 = 0.0, v64 = 0.0;
+        uint32_t hit_prim = c.prim;
+        float hit_t = c.t, hit_u = c.u, hit_v = c.v;
+        if (s.exact) {
+            g_x_nodes += 1;
+            // (the same two steps as rt_kernel.h: selection in f64 among what FP32 could not order and for every
+            // node that spawns children; then, for a hit that stands, the pattern / edge decisions)
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                bool amb = c.unsure || c.alt != kNoPrim;
+                bool why_children = false;
+                const bool why_pattern = false, why_edge = false;
+                if (c.prim != kNoPrim) {
+                    const DMaterial& m = s.ps.mats[s.ps.recs[c.prim].material];
+                    why_children = cur.depth > 0 && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
+                }
+                if (!(amb || why_children)) break;
+                XCandidates<4> xc;
+                const uint32_t a = c.prim, b = c.alt;  // entered in world.objects order
+                const bool a_first = b == kNoPrim || (a != kNoPrim && s.ps.order[a] < s.ps.order[b]);
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t pr = (k == 0) == a_first ? a : b;
+                    if (pr == kNoPrim) continue;
+                    const DPrim& p = s.ps.recs[pr];
+                    xc.set(k, xintersect(p.type, s.ps.xprims[pr].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64), pr);
+                }
+                uint32_t pr = kNoPrim;
+                if (xc.hit(t64, pr, u64, v64)) {
+                    g_x_refined += 1, g_x_children += why_children, g_x_pattern += why_pattern, g_x_amb += amb, g_x_edge += why_edge;
+                    g_x_changed += (pr != c.prim) ? 1u : 0u;
+                    refined = true;
+                    hit_prim = pr, hit_t = static_cast<float>(t64), hit_u = static_cast<float>(u64), hit_v = static_cast<float>(v64);
+                    break;
+                }
+                // f64 finds none of the candidates in front of the ray: search again without them
+                g_x_retry += 1;
+                hit_prim = kNoPrim;
+                if (attempt == 1) break;
+                c = closest_hit(s, cur.ray, a, b);
+                hit_prim = c.prim, hit_t = c.t, hit_u = c.u, hit_v = c.v;
+            }
+        }
+        if (hit_prim != kNoPrim) {
+            const DPrim& p = s.ps.recs[hit_prim];
             const DMaterial& m = s.ps.mats[p.material];
-            HitInfo h = prepare_hit(p, s.ps.extras.data(), cur.ray, cur.ray.self == c.prim, c.t, c.u, c.v);
+            HitInfo h = prepare_hit(p, ex, cur.ray, cur.ray.self == hit_prim, hit_t, hit_u, hit_v);
             V3 over = h.p + h.n * kEps;
             V3 pc = pattern_color(s.ps.pats[m.pattern], h.q + h.dq);
+            if (s.exact && !refined) {
+                const bool why_pattern = pattern_unsure(s.ps.pats[m.pattern], h.q + h.dq, h.eq);
+                if (why_pattern || h.edge) {
+                    XCandidates<4> xc;
+                    xc.set(0, xintersect(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64), hit_prim);
+                    uint32_t pr = kNoPrim;
+                    refined = xc.hit(t64, pr, u64, v64);
+                    if (refined) g_x_refined += 1, g_x_pattern += why_pattern, g_x_edge += h.edge;
+                }
+            }
+            if (refined) {  // the reference's own hit geometry (rt_exact.h)
+                xh = xprepare(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64, t64, u64, v64);
+                over = to_v3(xh.over), h.n = to_v3(xh.normal), h.inside = xh.inside, h.p = to_v3(xh.point);
+                const DPattern& pat = s.ps.pats[m.pattern];
+                double frac;
+                const bool is_a = xpattern_is_a(pat.type, s.ps.xprims[hit_prim].inv, s.ps.xpats[m.pattern].inv, xh.over, frac);
+                const V3 ca = v3(pat.a[0], pat.a[1], pat.a[2]), cb = v3(pat.b[0], pat.b[1], pat.b[2]);
+                pc = pat.type == PAT_GRADIENT ? ca + (cb - ca) * static_cast<float>(frac) : (is_a ? ca : cb);
+            }
             V3 surface = v3(0, 0, 0);
             double lit_by_light[4] = {-1.0, -1.0, -1.0, -1.0};
             for (uint32_t li = 0; li < s.ps.n_lights; ++li) {
@@ -287,7 +382,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                 V3 lc = v3(l.color[0], l.color[1], l.color[2]);
                 V3 ec = pc * lc;
                 uint32_t cells = l.usteps * l.vsteps;
-                if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, c.prim, m.shininess);
+                if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, hit_prim, m.shininess);
                 uint32_t lit = 0;
                 float sum_d = 0.0f, sum_s = 0.0f;
                 for (uint32_t cell = 0; cell < cells; ++cell) {
@@ -301,7 +396,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     bool shadowed = false;
                     if (!(fabsf(dist) <= kEps)) {  // null vector => not shadowed (world.rs:77-81)
                         Ray sr;
-                        sr.o = over, sr.d = tl * (1.0f / dist), sr.self = c.prim, sr.q = h.q, sr.dq = h.dq;
+                        sr.o = over, sr.d = tl * (1.0f / dist), sr.self = hit_prim, sr.q = h.q, sr.dq = h.dq;
                         shadowed = occluded(s, sr, dist);
                     }
                     if (!shadowed) ++lit;
@@ -318,22 +413,31 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             acc = acc + cur.w * surface;
             if (debug)
                 std::printf("  [sim] node=%u depth=%u t=%.9g prim=%u type=%u p=(%.9g %.9g %.9g) n=(%.9g %.9g %.9g) inside=%d surf=(%.9g %.9g %.9g) w=(%.6g %.6g %.6g)\n",
-                            cur.node, cur.depth, c.t, c.prim, p.type, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, int(h.inside), surface.x,
+                            cur.node, cur.depth, hit_t, hit_prim, p.type, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, int(h.inside), surface.x,
                             surface.y, surface.z, cur.w.x, cur.w.y, cur.w.z);
 
             // children (world.rs:59-69,94-133); the per-light duplication becomes a factor n_lights
             bool want_refl = !(fabsf(m.reflectivity) <= kEps) && cur.depth > 0;
             bool want_refr = !(fabsf(m.transparency) <= kEps) && cur.depth > 0;
             float n1 = 1.0f, n2 = 1.0f;
+            uint32_t n1_prim = kNoPrim, n2_prim = kNoPrim;
             bool use_schlick = (m.reflectivity * m.transparency) > 0.0f;
-            if (cur.depth > 0 && m.transparency > 0.0f) containers(s, cur.ray, c.prim, c.t, m.ior, n1, n2);
+            if (cur.depth > 0 && m.transparency > 0.0f) containers(s, cur.ray, hit_prim, hit_t, m.ior, n1, n2, n1_prim, n2_prim);
             if (debug) std::printf("        n1=%.6g n2=%.6g\n", n1, n2);
             V3 rdir = v3(0, 0, 0);
-            if (want_refr && !refract_dir(h.eye, h.n, n1, n2, rdir)) want_refr = false;
+            D3 rdir64 = d3(0, 0, 0);
+            if (refined) {  // world.rs:109-130 in f64, with the f64 indices of the records the container pass named
+                const double x1 = n1_prim == kNoPrim ? 1.0 : s.ps.xior[s.ps.recs[n1_prim].material];
+                const double x2 = n2_prim == kNoPrim ? 1.0 : s.ps.xior[s.ps.recs[n2_prim].material];
+                if (want_refr && !xrefract(xh, x1, x2, rdir64)) want_refr = false;
+                rdir = to_v3(rdir64);
+            } else if (want_refr && !refract_dir(h.eye, h.n, n1, n2, rdir)) {
+                want_refr = false;
+            }
             if (trace) {  // census: the same 24-double event the oracle records (rt_oracle.hpp kTraceEventDoubles)
-                const double ev[24] = {double(cur.node), c.t, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, h.inside ? 1.0 : 0.0, n1, n2,
+                const double ev[24] = {double(cur.node), hit_t, h.p.x, h.p.y, h.p.z, h.n.x, h.n.y, h.n.z, h.inside ? 1.0 : 0.0, n1, n2,
                                        pc.x, pc.y, pc.z, lit_by_light[0], lit_by_light[1], lit_by_light[2], lit_by_light[3],
-                                       want_refl ? 1.0 : 0.0, want_refr ? 1.0 : 0.0, double(p.type), 0, 0, 0};
+                                       want_refl ? 1.0 : 0.0, want_refr ? 1.0 : 0.0, double(p.type), refined ? 1.0 : 0.0, 0, 0};
                 trace->insert(trace->end(), ev, ev + 24);
             }
             float fr = use_schlick ? schlick(h.eye, h.n, n1, n2) : 0.0f;
@@ -342,12 +446,16 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             PathNode refl, refr;
             if (want_refl) {
                 refl.ray.o = over, refl.ray.d = cur.ray.d - h.n * 2.0f * dot(cur.ray.d, h.n);
-                refl.ray.self = c.prim, refl.ray.q = h.q, refl.ray.dq = h.dq;
+                refl.o64 = to_d3(refl.ray.o), refl.d64 = to_d3(refl.ray.d);
+                if (refined) refl.o64 = xh.over, refl.d64 = xh.reflectv, refl.ray.d = to_v3(xh.reflectv);
+                refl.ray.self = hit_prim, refl.ray.q = h.q, refl.ray.dq = h.dq;
                 refl.w = cur.w * k_refl, refl.depth = cur.depth - 1, refl.node = 2 * cur.node + 1;
             }
             if (want_refr) {
                 refr.ray.o = h.p - h.n * kEps, refr.ray.d = rdir;
-                refr.ray.self = c.prim, refr.ray.q = h.q, refr.ray.dq = neg(h.dq);
+                refr.o64 = to_d3(refr.ray.o), refr.d64 = to_d3(refr.ray.d);
+                if (refined) refr.o64 = xh.under, refr.d64 = rdir64, refr.ray.o = to_v3(xh.under);
+                refr.ray.self = hit_prim, refr.ray.q = h.q, refr.ray.dq = neg(h.dq);
                 refr.w = cur.w * k_refr, refr.depth = cur.depth - 1, refr.node = 2 * cur.node + 2;
             }
             if (want_refl && want_refr) {
@@ -382,6 +490,8 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
         return rc;
     }
     s.cam = pack_camera(*camera);
+    s.cam64 = pack_camera64(*camera);
+    s.exact = s.ps.has_f64 && camera->has_f64 != 0 && !(options && (options->flags & RT_FLAG_F32_ONLY));
     s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
     s.jitter_mode = options ? options->jitter_mode : 0u;
     s.seed = options ? options->seed : 0u;
@@ -424,6 +534,8 @@ extern "C" int hostsim_trace_pixels(const rt_scene_desc* desc, const rt_camera_d
     int rc = pack_scene(desc, s.ps, err);
     if (rc != RT_OK) return rc;
     s.cam = pack_camera(*camera);
+    s.cam64 = pack_camera64(*camera);
+    s.exact = s.ps.has_f64 && camera->has_f64 != 0 && !(options && (options->flags & RT_FLAG_F32_ONLY));
     s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
     s.jitter_mode = options ? options->jitter_mode : 0u;
     s.seed = options ? options->seed : 0u;
@@ -450,6 +562,18 @@ extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc
     const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
     g_tie_audit = false;
     out[0] = g_tie_hits, out[1] = g_tie_differs, out[2] = g_tie_wide_used;
+    return rc;
+}
+
+// Renders like hostsim_render and reports what the exact chain did: out[0] = path nodes, out[1] = nodes refined
+// in f64, out[2..5] = of those: because of children / a pattern boundary / an ambiguous search / an edge
+// (reasons overlap), out[6] = nodes whose primitive changed, out[7] = searches repeated without the candidates.
+extern "C" int hostsim_exact_stats(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options, float* rgb_out,
+                                   uint64_t* out, char* err_out, int err_cap) {
+    g_x_nodes = 0, g_x_refined = 0, g_x_children = 0, g_x_pattern = 0, g_x_amb = 0, g_x_edge = 0, g_x_changed = 0, g_x_retry = 0;
+    const int rc = hostsim_render(desc, camera, options, rgb_out, err_out, err_cap);
+    out[0] = g_x_nodes, out[1] = g_x_refined, out[2] = g_x_children, out[3] = g_x_pattern, out[4] = g_x_amb, out[5] = g_x_edge;
+    out[6] = g_x_changed, out[7] = g_x_retry;
     return rc;
 }
 

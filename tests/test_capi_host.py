@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     # field order/size as in include/rt_amd.h (natural C alignment on x86-64)
-    assert C.sizeof(RtCameraDesc) == 4 * 5 + 4 * 12
+    assert C.sizeof(RtCameraDesc) == 4 * 5 + 4 * 12 + 4 + 8 * 15  # f32 fields, has_f64, 15 doubles
     assert C.sizeof(RtOptions) == 7 * 4
-    assert C.sizeof(RtSceneDesc) == 8 + 5 * 8 + 21 * 8  # (abi_version, n_prims) + 5 padded counts + 21 pointers
+    assert C.sizeof(RtSceneDesc) == 8 + 5 * 8 + 25 * 8  # (abi_version, n_prims) + 5 padded counts + 25 pointers
 
 
 def _arr(ptr, ctype, shape):
@@ -79,7 +79,7 @@ def test_option_and_camera_validation():
     o.tile_rows, o.tile_first, o.tile_stride = 8, 2, 2
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     o = RtOptions()
-    o.flags = 2  # an unknown bit (1 = RT_FLAG_GLOBAL_ROWS)
+    o.flags = 4  # an unknown bit (1 = RT_FLAG_GLOBAL_ROWS, 2 = RT_FLAG_F32_ONLY)
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     assert L.rt_output_rows(None, None, C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     assert L.rt_render(None, C.byref(cam), None, None, None) == RT_ERR_BAD_ARGUMENT
