@@ -100,11 +100,13 @@ RT_HD void xcamera_ray(const XCamera& c, uint32_t x, uint32_t y, D3& origin, D3&
     dir = n;
 }
 
-// The intersections of ONE primitive with the f64 ray, in the order the reference pushes them.
+// The intersections of ONE primitive with the f64 ray in fixed slots, in the order the reference pushes
+// them (a cylinder: wall roots 0 and 1, caps 2 and 3; the others: 0 and 1); an absent one is +inf.  Every
+// index is a compile-time constant, so the slots are registers.
 struct XHits {
     double t[4], u, v;
-    int n;
 };
+constexpr double kAbsent = static_cast<double>(INFINITY);
 // cube.rs:79-97
 RT_HD void xcheck_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
     const double tmin_num = mn - origin, tmax_num = mx - origin;
@@ -135,16 +137,16 @@ RT_HD bool xcheck_cap(D3 o, D3 d, double t) {  // cylinder.rs:220-225
 RT_HD void xcaps(D3 o, D3 d, double ymin, double ymax, bool closed, XHits& h) {  // cylinder.rs:186-217
     if (!closed || xapprox(d.y, 0.0)) return;
     double t = (ymin - o.y) / d.y;
-    if (xcheck_cap(o, d, t)) h.t[h.n++] = t;
+    if (xcheck_cap(o, d, t)) h.t[2] = t;
     t = (ymax - o.y) / d.y;
-    if (xcheck_cap(o, d, t)) h.t[h.n++] = t;
+    if (xcheck_cap(o, d, t)) h.t[3] = t;
 }
 // EXOTIC = false compiles the cylinder / triangle code out (rt_math.h intersect_prim does the same).
 template <bool EXOTIC = true>
 RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro, D3 rd) {
     XHits h;
-    h.n = 0, h.u = 0.0, h.v = 0.0;
-    h.t[0] = h.t[1] = h.t[2] = h.t[3] = 0.0;
+    h.u = 0.0, h.v = 0.0;
+    h.t[0] = h.t[1] = h.t[2] = h.t[3] = kAbsent;
     const D3 o = xpoint(inv, ro), d = xvector(inv, rd);  // shape.rs:79-81, ray.rs:17-22
     switch (type) {
         case PRIM_SPHERE: {  // sphere.rs:38-72
@@ -155,11 +157,10 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
             if (disc < 0.0) break;
             h.t[0] = (-b - sqrt(disc)) / (2.0 * a);
             h.t[1] = (-b + sqrt(disc)) / (2.0 * a);
-            h.n = 2;
             break;
         }
         case PRIM_PLANE:  // plane.rs:39-51
-            if (!xapprox(d.y, 0.0)) h.t[0] = -o.y / d.y, h.n = 1;
+            if (!xapprox(d.y, 0.0)) h.t[0] = -o.y / d.y;
             break;
         case PRIM_CUBE: {  // cube.rs:39-76,101-122
             double x0, x1, y0, y1, z0, z1;
@@ -168,7 +169,7 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
             xcheck_axis(o.z, d.z, -1.0, 1.0, z0, z1);
             const double tmin = xmax_by3(x0, y0, z0), tmax = xmin_by3(x1, y1, z1);
             if (tmin > tmax) break;
-            h.t[0] = tmin, h.t[1] = tmax, h.n = 2;
+            h.t[0] = tmin, h.t[1] = tmax;
             break;
         }
         case PRIM_CYLINDER: {  // cylinder.rs:126-170
@@ -190,9 +191,9 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
                 t0 = t1, t1 = s;
             }
             const double y0 = o.y + t0 * d.y;
-            if (ymin < y0 && y0 < ymax) h.t[h.n++] = t0;
+            if (ymin < y0 && y0 < ymax) h.t[0] = t0;
             const double y1 = o.y + t1 * d.y;
-            if (ymin < y1 && y1 < ymax) h.t[h.n++] = t1;
+            if (ymin < y1 && y1 < ymax) h.t[1] = t1;
             xcaps(o, d, ymin, ymax, closed, h);
             break;
         }
@@ -209,7 +210,7 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
             const D3 oxe0 = xcross(p0, e0);
             const double v = f * xdot(d, oxe0);
             if (v < 0.0 || (u + v) > 1.0) break;
-            h.t[0] = f * xdot(e1, oxe0), h.u = u, h.v = v, h.n = 1;
+            h.t[0] = f * xdot(e1, oxe0), h.u = u, h.v = v;
             break;
         }
     }
@@ -218,8 +219,9 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
 
 // Intersection::sort + hit (intersection.rs:105-120) over the intersections of up to two candidate
 // primitives, entered in world.objects order: approximate comparator, insertion sort (stable), the
-// first t > 0.0 wins.  K slots per primitive (2 without cylinders; absent = +inf, which sorts last and
-// never wins); every index is a compile-time constant so that the lists stay in registers.
+// first t > 0.0 wins.  K slots per primitive (absent = +inf, which sorts last and never wins); every index
+// is a compile-time constant so that the lists stay in registers.
+RT_HD bool xless(double a, double b) { return !(fabs(a - b) <= kEpsD) && a < b; }  // (inf - inf = NaN: not less, like approx)
 template <int K>
 struct XCandidates {
     static constexpr int N = 2 * K;
@@ -228,14 +230,13 @@ struct XCandidates {
     int who[N];  // which of the two primitives an entry belongs to
     RT_HD XCandidates() {
 #pragma unroll
-        for (int i = 0; i < N; ++i) t[i] = static_cast<double>(INFINITY), who[i] = i / K;
+        for (int i = 0; i < N; ++i) t[i] = kAbsent, who[i] = i / K;
         prim[0] = prim[1] = kNoPrim, u[0] = u[1] = v[0] = v[1] = 0.0;
     }
     RT_HD void set(int which, const XHits& h, uint32_t prim_id) {  // which = 0 first, then 1
         prim[which] = prim_id, u[which] = h.u, v[which] = h.v;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (k < h.n) t[which * K + k] = h.t[k];
+        for (int k = 0; k < K; ++k) t[which * K + k] = h.t[k];
     }
     RT_HD bool hit(double& t_out, uint32_t& prim_out, double& u_out, double& v_out) {
 #pragma unroll
@@ -245,7 +246,7 @@ struct XCandidates {
             bool moving = true;
 #pragma unroll
             for (int j = i; j > 0; --j) {
-                const bool shift = moving && (!xapprox(kt, t[j - 1]) && kt < t[j - 1]);
+                const bool shift = moving && xless(kt, t[j - 1]);
                 if (shift) t[j] = t[j - 1], who[j] = who[j - 1];
                 else if (moving) t[j] = kt, who[j] = kw, moving = false;
             }
@@ -254,13 +255,48 @@ struct XCandidates {
         bool found = false;
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            if (!found && t[i] > 0.0 && t[i] < static_cast<double>(INFINITY)) {
+            if (!found && t[i] > 0.0 && t[i] < kAbsent) {
                 found = true;
                 t_out = t[i], prim_out = who[i] ? prim[1] : prim[0], u_out = who[i] ? u[1] : u[0], v_out = who[i] ? v[1] : v[0];
             }
         return found;
     }
 };
+// The same for ONE primitive without cylinder caps (at most two intersections, pushed t[0] then t[1]).
+RT_HD bool xhit_of_one(const XHits& h, double& t_out) {
+    const bool swap = xless(h.t[1], h.t[0]);
+    const double a = swap ? h.t[1] : h.t[0], b = swap ? h.t[0] : h.t[1];
+    if (a > 0.0 && a < kAbsent) {
+        t_out = a;
+        return true;
+    }
+    if (b > 0.0 && b < kAbsent) {
+        t_out = b;
+        return true;
+    }
+    return false;
+}
+// Nearest hit among one or two candidate primitives (second_type = REC_NODE: none), picking the smallest
+// network that holds their intersections.
+template <bool EXOTIC>
+RT_HD bool xselect(const XHits& ha, uint32_t prim_a, uint32_t type_a, const XHits& hb, uint32_t prim_b, uint32_t type_b, bool two,
+                   double& t_out, uint32_t& prim_out, double& u_out, double& v_out) {
+    const bool caps = EXOTIC && (type_a == PRIM_CYLINDER || (two && type_b == PRIM_CYLINDER));
+    if (!two && !caps) {
+        prim_out = prim_a, u_out = ha.u, v_out = ha.v;
+        return xhit_of_one(ha, t_out);
+    }
+    if (!caps) {
+        XCandidates<2> xc;
+        xc.set(0, ha, prim_a);
+        xc.set(1, hb, prim_b);
+        return xc.hit(t_out, prim_out, u_out, v_out);
+    }
+    XCandidates<4> xc;
+    xc.set(0, ha, prim_a);
+    if (two) xc.set(1, hb, prim_b);
+    return xc.hit(t_out, prim_out, u_out, v_out);
+}
 
 // intersection.rs:40-69 + shape.rs:83-96,118-137 + the shapes' local normals
 struct XHit {
@@ -315,6 +351,12 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
     return h;
 }
 
+// `|f % 2| <= 1e-5` (pattern.rs:74,82,89) for an integer-valued f (a floor, or a sum of floors): |f % 2| is
+// 0 or 1, so the test says "f is even" — halving and flooring are exact; inf / NaN give false like fmod.
+RT_HD bool xeven(double f) {
+    const double h = 0.5 * f;
+    return h - floor(h) == 0.0;
+}
 // pattern.rs:58-96 at the over point (material.rs:127): object space, then pattern space.  Returns
 // whether colour a applies (Solid: always; Gradient: `frac` receives the blend factor instead).
 RT_HD bool xpattern_is_a(uint32_t pat_type, const double* prim_inv, const double* pat_inv, D3 over, double& frac) {
@@ -322,10 +364,10 @@ RT_HD bool xpattern_is_a(uint32_t pat_type, const double* prim_inv, const double
     if (pat_type == PAT_SOLID) return true;
     const D3 pp = xpoint(pat_inv, xpoint(prim_inv, over));
     switch (pat_type) {
-        case PAT_STRIPE: return xapprox(fmod(floor(pp.x), 2.0), 0.0);
+        case PAT_STRIPE: return xeven(floor(pp.x));
         case PAT_GRADIENT: frac = pp.x - floor(pp.x); return true;
-        case PAT_RING: return xapprox(fmod(floor(hypot(pp.x, pp.z)), 2.0), 0.0);
-        default: return xapprox(fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0), 0.0);
+        case PAT_RING: return xeven(floor(hypot(pp.x, pp.z)));
+        default: return xeven(floor(pp.x) + floor(pp.y) + floor(pp.z));
     }
 }
 

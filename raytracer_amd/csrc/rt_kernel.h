@@ -331,8 +331,11 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
 #ifndef RT_MIN_BLOCKS_PLAIN
 #define RT_MIN_BLOCKS_PLAIN 5
 #endif
-constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA) {
-    return !AREA ? RT_MIN_BLOCKS_PLAIN : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
+#ifndef RT_MIN_BLOCKS_PLAIN_X
+#define RT_MIN_BLOCKS_PLAIN_X 5  // the same kernels with the f64 chain (EXACT)
+#endif
+constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT) {
+    return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
 }
 // EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
 // in f64 and the nodes that decide something are worked out again with the reference's formulas (rt_exact.h).
@@ -340,7 +343,7 @@ struct Ray64 {
     D3 o, d;
 };
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT>
-__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) void render_kernel(const KParams P) {
+__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT)) void render_kernel(const KParams P) {
 #ifdef RT_ORDER
     constexpr uint32_t kOrder = RT_ORDER;  // experiments
 #else
@@ -380,10 +383,12 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
     auto cur64 = [&]() {
         Ray64 r;
         if (node == 0u) {
-            uint32_t l2 = threadIdx.x & 63u;
-            asm volatile("" : "+v"(l2));  // (recomputed like the final store's coordinates, not kept live)
+            // (No inline asm here, unlike the final store's recomputation: inside the path loop an
+            // `asm volatile` counts as a possible write to memory, the compiler then no longer treats the
+            // scene tables as unclobbered, and every record of the walks comes through a VECTOR load instead of
+            // a scalar one — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
             uint32_t px, pyl, pgy;
-            pixel_of_lane(P, kOrder, wave, l2, px, pyl, pgy);
+            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
             xcamera_ray(P.cam64, px, pgy, r.o, r.d);
         } else {
             r = r64[cur_slot];
@@ -412,9 +417,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
         uint32_t alt_prim = kNoPrim, excl0 = kNoPrim, excl1 = kNoPrim;
         float alt_t = INFINITY;
         double t64 = 0.0, u64 = 0.0, v64 = 0.0;
-        // (The search and the f64 selection are written out as two calls each rather than as a loop: inside
-        // a loop the compiler no longer proves the walk's record index wave-uniform and the records come
-        // through vector loads — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
+        // (The search and the f64 selection are two calls each, the second one rare.)
         auto do_trace = [&](bool live) {
             auto trace_enter = [&](uint32_t, const DPrim& nd) {
                 return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + (EXACT ? amb_window(hit_t) : tie_window(hit_t)));
@@ -466,21 +469,21 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
             }
             bool retry = false;
             if (live && (hit_unsure || alt_prim != kNoPrim || spawns)) {
-                XCandidates<EXOTIC ? 4 : 2> xc;
                 const Ray64 r = cur64();
                 const uint32_t a = hit_prim, b = alt_prim;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
-                const uint32_t first = a_first ? a : b, second = a_first ? b : a;
-                if (first != kNoPrim) {
-                    const DPrim p = sc.recs[first];
-                    xc.set(0, xintersect<EXOTIC>(p.type, sc.xprims[first].inv, sc.xextras[p.extra].f, r.o, r.d), first);
-                }
-                if (second != kNoPrim) {
-                    const DPrim p = sc.recs[second];
-                    xc.set(1, xintersect<EXOTIC>(p.type, sc.xprims[second].inv, sc.xextras[p.extra].f, r.o, r.d), second);
+                const uint32_t first = a_first ? a : b, second = a_first ? b : a;  // first is never kNoPrim here
+                const DPrim pa = sc.recs[first];
+                const XHits ha = xintersect<EXOTIC>(pa.type, sc.xprims[first].inv, sc.xextras[pa.extra].f, r.o, r.d);
+                XHits hb = ha;
+                uint32_t type_b = REC_NODE;
+                if (second != kNoPrim) {  // rare: a second candidate
+                    const DPrim pb = sc.recs[second];
+                    type_b = pb.type;
+                    hb = xintersect<EXOTIC>(pb.type, sc.xprims[second].inv, sc.xextras[pb.extra].f, r.o, r.d);
                 }
                 uint32_t pr = kNoPrim;
-                if (xc.hit(t64, pr, u64, v64)) {
+                if (xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64)) {
                     refined = true;
                     hit_prim = pr, hit_t = static_cast<float>(t64), hit_u = static_cast<float>(u64), hit_v = static_cast<float>(v64);
                 } else {
@@ -566,10 +569,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA)) v
             const double* xinv = sc.xprims[hit_prim].inv;
             const Ray64 r = cur64();
             if (!refined) {  // (late: the same primitive's f64 hit; if f64 finds none the FP32 hit stands)
-                XCandidates<EXOTIC ? 4 : 2> xc;
-                xc.set(0, xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d), hit_prim);
+                const XHits ha = xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d);
                 uint32_t pr = kNoPrim;
-                refined = xc.hit(t64, pr, u64, v64);
+                refined = xselect<EXOTIC>(ha, hit_prim, p.type, ha, kNoPrim, REC_NODE, false, t64, pr, u64, v64);
             }
           if (refined) {
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);

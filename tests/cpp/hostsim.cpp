@@ -325,17 +325,20 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     why_children = cur.depth > 0 && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
                 }
                 if (!(amb || why_children)) break;
-                XCandidates<4> xc;
                 const uint32_t a = c.prim, b = c.alt;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && s.ps.order[a] < s.ps.order[b]);
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t pr = (k == 0) == a_first ? a : b;
-                    if (pr == kNoPrim) continue;
-                    const DPrim& p = s.ps.recs[pr];
-                    xc.set(k, xintersect(p.type, s.ps.xprims[pr].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64), pr);
+                const uint32_t first = a_first ? a : b, second = a_first ? b : a;
+                const DPrim& pa = s.ps.recs[first];
+                const XHits ha = xintersect(pa.type, s.ps.xprims[first].inv, s.ps.xextras[pa.extra].f, cur.o64, cur.d64);
+                XHits hb = ha;
+                uint32_t type_b = REC_NODE;
+                if (second != kNoPrim) {
+                    const DPrim& pb = s.ps.recs[second];
+                    type_b = pb.type;
+                    hb = xintersect(pb.type, s.ps.xprims[second].inv, s.ps.xextras[pb.extra].f, cur.o64, cur.d64);
                 }
                 uint32_t pr = kNoPrim;
-                if (xc.hit(t64, pr, u64, v64)) {
+                if (xselect<true>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64)) {
                     g_x_refined += 1, g_x_children += why_children, g_x_pattern += why_pattern, g_x_amb += amb, g_x_edge += why_edge;
                     g_x_changed += (pr != c.prim) ? 1u : 0u;
                     refined = true;
@@ -359,10 +362,9 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             if (s.exact && !refined) {
                 const bool why_pattern = pattern_unsure(s.ps.pats[m.pattern], h.q + h.dq, h.eq);
                 if (why_pattern || h.edge) {
-                    XCandidates<4> xc;
-                    xc.set(0, xintersect(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64), hit_prim);
+                    const XHits ha = xintersect(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64);
                     uint32_t pr = kNoPrim;
-                    refined = xc.hit(t64, pr, u64, v64);
+                    refined = xselect<true>(ha, hit_prim, p.type, ha, kNoPrim, REC_NODE, false, t64, pr, u64, v64);
                     if (refined) g_x_refined += 1, g_x_pattern += why_pattern, g_x_edge += h.edge;
                 }
             }
