@@ -813,6 +813,12 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
         }
         case PRIM_PLANE:  // plane.rs:53-55
             q.y = 0.0f;
+            {  // t = -o.y / d.y is ill-conditioned for a grazing ray: its error moves the point along the ray
+                const float a = fabsf(p.inv[4] * ray.o.x) + fabsf(p.inv[5] * ray.o.y) + fabsf(p.inv[6] * ray.o.z) + fabsf(p.inv[7]);
+                const float b = fabsf(p.inv[4] * ray.d.x) + fabsf(p.inv[5] * ray.d.y) + fabsf(p.inv[6] * ray.d.z);
+                const float dt = 2e-7f * fmaf(fabsf(t), b, a) * rcp_f(fabsf(d.y));
+                h.eq.x = fmaf(fabsf(d.x), dt, h.eq.x), h.eq.z = fmaf(fabsf(d.z), dt, h.eq.z);
+            }
             h.eq.y = 0.0f;
             nobj = v3(0.0f, 1.0f, 0.0f);
             break;
@@ -841,11 +847,15 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             float dist = fmaf(q.x, q.x, q.z * q.z);
             float top = e[1] - kEps, bot = e[0] + kEps;
             h.edge = dist > 0.99f && (fabsf(q.y - e[1]) < kGraze || fabsf(q.y - e[0]) < kGraze);
+            // a cap is a plane: t = (cap - o.y) / d.y is ill-conditioned for a ray that grazes it (as for PRIM_PLANE)
+            const float cap_dt = 2e-7f * (fabsf(e[1]) + fabsf(e[0]) + fabsf(o.y) + fabsf(t * d.y)) * rcp_f(fabsf(d.y));
             if (dist < 1.0f && (approx(q.y, top) || q.y > top)) {
                 q.y = e[1];
+                h.eq.x = fmaf(fabsf(d.x), cap_dt, h.eq.x), h.eq.z = fmaf(fabsf(d.z), cap_dt, h.eq.z), h.eq.y = 0.0f;
                 nobj = v3(0.0f, 1.0f, 0.0f);
             } else if (dist < 1.0f && (approx(q.y, bot) || q.y < bot)) {
                 q.y = e[0];
+                h.eq.x = fmaf(fabsf(d.x), cap_dt, h.eq.x), h.eq.z = fmaf(fabsf(d.z), cap_dt, h.eq.z), h.eq.y = 0.0f;
                 nobj = v3(0.0f, -1.0f, 0.0f);
             } else {
                 float tc, half;
@@ -924,8 +934,10 @@ RT_HD bool pattern_unsure(const DPattern& pat, V3 p, V3 e_q) {
         return !(fminf(f, 1.0f - f) > r);  // NaN counts as near
     };
     switch (pat.type) {
-        case PAT_STRIPE:
-        case PAT_GRADIENT: return near(c[0], room[0]);
+        case PAT_STRIPE: return near(c[0], room[0]);
+        // (a gradient is continuous between its jumps, but its blend factor is the fractional part of a
+        // coordinate that FP32 only knows to room[0]: far from the pattern's origin that alone exceeds 1e-5)
+        case PAT_GRADIENT: return near(c[0], room[0]) || room[0] > 1e-5f;
         case PAT_RING: return near(sqrtf(fmaf(c[0], c[0], c[2] * c[2])), room[0] + room[2]);
         default: return near(c[0], room[0]) || near(c[1], room[1]) || near(c[2], room[2]);
     }

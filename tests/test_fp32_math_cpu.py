@@ -2,11 +2,14 @@
 host simulator, against the f64 oracle and the golden vectors.  This is what can be checked about
 the device code in a container without a GPU; the `-m gpu` tests repeat it on the real kernel.
 
-Bar (north_star): per-channel |f32 - f64| <= TOL = 1e-4.  FP32 cannot meet it on EVERY pixel: colour
-is a discontinuous function of position at pattern edges, shadow edges, silhouettes and at exact
-ties (a ray hitting the line where two planes meet), so a 1e-6 difference in a hit point flips a
-whole pixel.  The tests therefore bound the FRACTION of pixels above TOL per scene (every offending
-class is listed in DESIGN.md) and require that nearly all PNG bytes agree to <= 1 LSB.
+Bar (north_star): per-channel |f32 - f64| <= TOL = 1e-4.  FP32 alone cannot meet it on EVERY pixel:
+colour is a discontinuous function of position at pattern edges, shadow edges, silhouettes and at exact
+ties (a ray hitting the line where two planes meet), so a 1e-6 difference in a hit point flips a whole
+pixel, and deep glass paths magnify FP32 position error.  With the caller's f64 tables the f64 chain
+(raytracer_amd/csrc/rt_exact.h) decides those nodes like the reference: the golden frames then have NO pixel
+above TOL (round-2 census: <= 4e-6 of the pixels at the configs' full sizes, all of them shadow-ray edges).
+The FP32-only path (RT_FLAG_F32_ONLY, or a caller without f64 tables) keeps the round-1 bounds on the
+FRACTION of pixels above TOL.
 """
 import os
 
@@ -19,8 +22,8 @@ from raytracer_amd import ExampleScene, RtOptions
 TOL = 1e-4
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# max fraction of pixels with any channel off by more than TOL at 96x54 (edge pixels are a larger
-# share of a small image than of a 1080p one)
+# FP32-only path: max fraction of pixels with any channel off by more than TOL at 96x54 (edge pixels are
+# a larger share of a small image than of a 1080p one)
 BAD_FRAC = {
     "test_world": 0.0,
     "checkered_walls_metallic_sphere": 2e-3,
@@ -41,11 +44,25 @@ def _png_lsb_frac(test, ref):
 
 
 @pytest.mark.parametrize("name", H.SCENES)
-def test_fp32_formulation_matches_golden_images(name):
+def test_with_the_f64_chain_no_pixel_of_the_golden_images_is_off(name):
     ref = np.load(os.path.join(GOLDEN, "images.npz"))[name]
     h, w, _ = ref.shape
     ex = ExampleScene(name, w, h)
     sim = H.hostsim_render(ex, RtOptions())
+    c = H.compare(sim, ref, TOL)
+    assert c["bad_pixels"] == 0, c  # measured: max error 6e-8 .. 1.5e-5 over the nine scenes
+    assert np.median(np.abs(sim - ref)) <= 1e-6
+    assert _png_lsb_frac(sim, ref) == 0.0
+
+
+@pytest.mark.parametrize("name", H.SCENES)
+def test_fp32_only_formulation_matches_golden_images(name):
+    ref = np.load(os.path.join(GOLDEN, "images.npz"))[name]
+    h, w, _ = ref.shape
+    ex = ExampleScene(name, w, h)
+    opt = RtOptions()
+    opt.flags = 2  # RT_FLAG_F32_ONLY
+    sim = H.hostsim_render(ex, opt)
     c = H.compare(sim, ref, TOL)
     assert c["bad_frac"] <= BAD_FRAC[name], c
     assert np.median(np.abs(sim - ref)) <= 1e-6
@@ -63,7 +80,7 @@ def test_counter_rng_jitter_is_shared_with_the_oracle(name):
     opt.jitter_mode, opt.seed = 1, 3
     sim = H.hostsim_render(ExampleScene(name, w, h), opt)
     c = H.compare(sim, ref, TOL)
-    assert c["bad_frac"] <= BAD_FRAC[name] + 1e-3, c
+    assert c["bad_pixels"] == 0, c
     centre = np.load(os.path.join(GOLDEN, "images.npz"))[name]
     assert np.abs(sim - centre).max() > 1e-3  # the jitter really moved the samples
 
@@ -102,4 +119,4 @@ def test_full_resolution_probes_cover_image():
         row = H.hostsim_render(ex, o)[0]
         for k in np.nonzero(xy[:, 1] == y)[0]:
             bad += int(np.abs(row[xy[k, 0]] - rgb[k]).max() > TOL)
-    assert bad <= 1
+    assert bad == 0

@@ -1,9 +1,11 @@
 """Parity of the HIP render path against the f64 oracle, THROUGH THE C ABI (librt_amd.so), on a real
-MI355X.  Bar: per-channel |f32 - f64| <= TOL = 1e-4 (north_star); colour is discontinuous at
-pattern/shadow edges, silhouettes and exact ties, so the tests bound the FRACTION of pixels above
-TOL (classes listed in DESIGN.md) and also require the kernel to agree with the scalar FP32
-executable spec (tests/cpp/hostsim.cpp) to 1e-5 on all but the same few discontinuity pixels —
-i.e. every outlier is an FP32-formulation outlier, none comes from the wave-level orchestration."""
+MI355X.  Bar: per-channel |f32 - f64| <= TOL = 1e-4 (north_star) on all but 1e-5 of the pixels (SURVEY.md
+§8d).  With the f64 chain (rt_exact.h; the example scenes carry the caller's f64 tables) the round-2 census
+at the configs' full sizes leaves 0 - 4e-6 of the pixels above TOL, all at shadow-ray edges
+(profiles/r02_parity_census.txt); the limits below are those measurements plus margin.  The FP32-only path
+(RT_FLAG_F32_ONLY) keeps the round-1 limits on the FRACTION of pixels above TOL.  The kernel must also agree
+with the scalar executable spec of the same arithmetic (tests/cpp/hostsim.cpp) to 1e-5 on all but a few
+discontinuity pixels — i.e. no outlier comes from the wave-level orchestration."""
 import ctypes as C
 import os
 
@@ -18,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BAD_FRAC = {  # same limits as tests/test_fp32_math_cpu.py (96x54 images)
+BAD_FRAC = {  # FP32-only path: same limits as tests/test_fp32_math_cpu.py (96x54 images)
     "test_world": 0.0, "checkered_walls_metallic_sphere": 2e-3, "striped_sphere_multiple_lights": 2e-3,
     "glass_sphere_checkered_floor_aerial_view": 4e-3, "multiple_glass_and_metallic_spheres": 4e-3,
     "cover_image": 1e-3, "cover_image_area": 1e-3, "shapes_zoo": 2e-2, "obj_mesh": 2e-3,
@@ -45,12 +47,21 @@ def test_golden_images(name):
     h, w, _ = ref.shape
     img, _ = _render(name, w, h)
     c = H.compare(img, ref, TOL)
-    assert c["bad_frac"] <= BAD_FRAC[name], c
+    assert c["bad_pixels"] <= 1, c  # measured 0 on all nine (a shadow-edge pixel may flip with the 1-ulp rcp)
     assert np.median(np.abs(img - ref)) <= 1e-6
     # against the scalar executable spec of the same arithmetic: identical up to the hardware's 1-ulp
     # rcp/sqrt/rsq (the host divides exactly), which can flip a discontinuity pixel but nothing else
     sim = H.hostsim_render(ExampleScene(name, w, h), RtOptions())
     d = np.abs(img - sim).max(axis=-1)
+    assert np.median(d) <= 1e-6 and (d > 1e-5).mean() <= 1e-3, float(d.max())
+    # the FP32-only path: the round-1 limits
+    o = RtOptions()
+    o.flags = 2  # RT_FLAG_F32_ONLY
+    img32, st32 = _render(name, w, h, o, stats=True)
+    c = H.compare(img32, ref, TOL)
+    assert c["bad_frac"] <= BAD_FRAC[name] and st32.exact_nodes == 0, c
+    sim32 = H.hostsim_render(ExampleScene(name, w, h), o)
+    d = np.abs(img32 - sim32).max(axis=-1)
     assert np.median(d) <= 1e-6 and (d > 1e-5).mean() <= BAD_FRAC[name] + 1e-3, float(d.max())
 
 
@@ -63,7 +74,7 @@ def test_counter_rng_images(name):
     opt.jitter_mode, opt.seed = 1, 3
     img, _ = _render(name, w, h, opt)
     c = H.compare(img, ref, TOL)
-    assert c["bad_frac"] <= BAD_FRAC[name] + 1e-3, c
+    assert c["bad_pixels"] <= 1, c
 
 
 def test_reference_end_to_end_pixel_and_host_api_path():
@@ -85,8 +96,31 @@ def test_full_resolution_probes(name):
     img, _ = _render(name, w, h)
     got = img[xy[:, 1], xy[:, 0]]
     bad = int((np.abs(got - rgb) > TOL).any(axis=1).sum())
-    assert bad <= {"shapes_zoo": 6}.get(name, 2), (bad, np.abs(got - rgb).max())
+    assert bad == 0, (bad, np.abs(got - rgb).max())  # measured: max 1e-7 .. 4e-6 per scene
     assert np.median(np.abs(got - rgb)) <= 1e-6
+
+
+# (scene, rows compared) — whole frames where the oracle takes about a second on the box, row blocks of the 4K ones
+CENSUS = [("checkered_walls_metallic_sphere", None), ("striped_sphere_multiple_lights", None),
+          ("glass_sphere_checkered_floor_aerial_view", None), ("multiple_glass_and_metallic_spheres", (900, 1200)),
+          ("cover_image", (700, 1300)), ("cover_image_area", (1000, 1080))]
+
+
+@pytest.mark.parametrize("name,rows", CENSUS)
+def test_full_resolution_census_meets_the_survey_bar(name, rows):
+    """at most 1e-5 of the pixels above 1e-4, at each config's FULL resolution, deterministic
+    jitter (the shared counter RNG for the area-light scenes): whole frames for the 720p/1080p configs, a block
+    of rows through the busiest part of the 4K ones (scripts/parity_census.py does the whole frames:
+    profiles/r02_parity_census.txt)."""
+    w, h = FULL[name]
+    opt = RtOptions()
+    opt.jitter_mode, opt.seed = (0, 0) if name in ("multiple_glass_and_metallic_spheres", "cover_image") else (1, 0)
+    img, st = _render(name, w, h, opt, stats=True)
+    r0, r1 = rows if rows else (0, h)
+    ref, _, _ = H.oracle_render(name, w, h, jitter=opt.jitter_mode, seed=0, threads=16, rows=(r0, r1))
+    c = H.compare(img[r0:r1], ref[r0:r1], TOL)
+    assert c["bad_pixels"] <= max(4, int(2e-5 * c["pixels"])), c  # measured: 0 - 4e-6; the bar is 1e-5
+    assert st.exact_nodes > 0 or name == "striped_sphere_multiple_lights"
 
 
 @pytest.mark.parametrize("name,world", [("striped_sphere_multiple_lights", 2), ("cover_image", 8),
@@ -226,10 +260,12 @@ def test_group_gates_on_the_device(box):
     assert np.median(dd) <= 1e-6 and (dd > 1e-5).mean() <= 2e-3
 
 
-def test_stochastic_scene_against_independent_jitter():
+@pytest.mark.parametrize("name", ["checkered_walls_metallic_sphere", "striped_sphere_multiple_lights",
+                                  "glass_sphere_checkered_floor_aerial_view", "cover_image_area"])
+def test_stochastic_scene_against_independent_jitter(name):
     """North-star bar for area-light scenes: RMSE against a render with INDEPENDENT jitter at the same
     sample count is within 1.1x the noise floor between two such independent renders."""
-    name, w, h = "checkered_walls_metallic_sphere", 320, 180
+    w, h = 320, 180
     o = RtOptions()
     o.jitter_mode, o.seed = 1, 1
     gpu, _ = _render(name, w, h, o)
