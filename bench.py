@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s and frame ms of the MI355X render path (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload NAME --width W --height H]
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME --width W --height H] [--no-also]
 
 A "step" is ONE FRAME of the workload: Camera::render of the scene at the config's resolution,
 scene tables and output image resident in HBM.  Default workload = BASELINE.json configs[1]:
 examples/striped_sphere_multiple_lights at 1920x1080 (as the example file is written: two AREA
-lights, 8x8 and 4x4 cells, jittered with the counter RNG, seed 0).  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the SAME frame is split into interleaved bands of 8 pixel
-rows (band b -> rank b mod N), every rank renders its bands with the scene replicated, and the frame
-is assembled in rank 0's HBM inside the timed region ("strong" scaling):
+lights, 8x8 and 4x4 cells, jittered with the counter RNG, seed 0), rendered with the f64 chain
+(raytracer_amd/csrc/rt_exact.h) — the mode whose output meets the parity bar.  With N > 1 (launched
+by torch.distributed.run, one rank per GPU) the SAME frame is split into interleaved bands of 8
+pixel rows (band b -> rank b mod N), every rank renders its bands with the scene replicated, and
+the frame is assembled in rank 0's HBM inside the timed region ("strong" scaling):
   * "p2p"   : rank 0 owns ONE shared frame (rt_frame_create), the other ranks map it
               (rt_frame_open, peer access over xGMI) and their kernels store their rows straight into
               it (RT_FLAG_GLOBAL_ROWS) — no collective and no staging copy on the data path; ranks
@@ -17,26 +18,39 @@ is assembled in rank 0's HBM inside the timed region ("strong" scaling):
   * "copy2d": the same shared frame, but every rank renders into its own HBM and then moves its bands
               with ONE strided device-to-device copy (hipMemcpy2DAsync, bands are 8 rows apart by N)
               — a bulk transfer instead of the kernel's 12-byte stores over the fabric.  Which of the
-              two is faster depends on the links; a few untimed frames of each decide (both leave the
-              same frame, and it is verified bit for bit either way);
+              two is faster depends on the links; a few untimed frames of each decide;
   * "gather": if the shared frame cannot be set up on every rank, the packed bands go through an RCCL
-              gather to rank 0 and are re-interleaved there (the round-1 path, kept as plumbing
-              fallback — both paths run the same kernels).
-`RT_BENCH_ASSEMBLY=p2p|copy2d` overrides that choice.  `RT_BENCH_SINGLE_DEVICE=1` (rehearsal on a one-GPU box) puts every rank on GPU 0 with a gloo control
-plane; it exercises the same inter-process frame sharing without xGMI.
+              gather to rank 0 and are re-interleaved there (plumbing fallback, same kernels).
+`RT_BENCH_ASSEMBLY=p2p|copy2d` overrides that choice.  `RT_BENCH_SINGLE_DEVICE=1` (rehearsal on a
+one-GPU box) puts every rank on GPU 0 with a gloo control plane; it exercises the same inter-process
+frame sharing without xGMI.  After the timed region the assembled frame is checked: the shared frame is
+filled with a sentinel, ONE frame is rendered in the chosen mode, and the result must equal the frame one
+GPU renders alone, bit for bit.
 
-Rank 0 prints ONE JSON line.  `value` = unique rays traced per second over the whole job
-(primary + reflection + refraction + shadow; the reference's own count is the same for this
-workload because nothing in it is reflective).  `roofline` compares the ALGORITHMIC FP32 flop rate of
-the render kernel (raytracer_amd/flopmodel.py) with the FP32 vector peak; the kernel
-time is measured with events on the stream the kernel is launched on.  `cpu_baseline` is the f64
-oracle (a restatement of the reference algorithm, NOT the Rust binary) timed on this host.
+Rank 0 prints ONE JSON line.
+  value     REFERENCE-EQUIVALENT rays per second over the whole job: every ray of the reference's accounting
+            for this frame (primary + reflection + refraction + one shadow ray per light cell of every
+            shaded hit, light.rs:192-209) divided by the frame time.  The kernel ANSWERS most shadow rays
+            without casting them (shaft tests, lights behind the surface): `config.rays_cast` is what it
+            really traced, `config.cast_share` the ratio, `value_cast` the rate of traced rays.
+  roofline  `frac` = EXECUTED FP32 vector flop/s over the 157.3 TFLOP/s peak: FP32 add/mul/fma/
+            transcendental wave-instructions counted by the hardware (rocprofv3 --pmc, scripts/
+            roofline_pmc.sh -> profiles/pmc.json, per launch of this workload's kernel) x 64 lanes
+            (x 2 for fma), divided by the kernel time measured live here with events on the launch
+            stream.  `valu_issue_frac`, `waves_per_simd`, `wait_frac`, `lane_util` come from the same
+            counters; `reference_equivalent` is the round-1 figure (the reference algorithm's flop for the
+            frame over the kernel time: credit for avoided work, not a hardware fraction).
+  also      the other BASELINE configs a multi-GPU run is about (C4 and cover-image at 3840x2160), timed in
+            the same run with the same partition and assembly.
+  sustained back-to-back frames for >= 0.3 s after the timed steps.
+  cpu_baseline  the f64 oracle (a restatement of the reference algorithm, NOT the Rust binary) on this host.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -61,7 +75,11 @@ WORKLOADS = {  # BASELINE.json configs (the scene files as written; SURVEY.md §
     "shapes_zoo": (1920, 1080),
     "obj_mesh": (1920, 1080),
 }
+ALSO = ["multiple_glass_and_metallic_spheres", "cover_image", "cover_image_area"]  # BASELINE configs 4 and 5
 BAND_ROWS = partition.BAND_ROWS
+COUNTER_NAMES = ["primary_rays", "reflection_rays", "refraction_rays", "shadow_rays", "shaded_hits", "light_cells",
+                 "pattern_lookups", "container_passes", "shadow_rays_cast", "exact_nodes"]
+N_CU, N_SIMD, CLOCK_HZ = 256, 4, 2.4e9  # MI355X_MICROARCH.md
 
 
 def parse_args():
@@ -74,7 +92,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--jitter", default="counter", choices=["counter", "center"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--f32-only", action="store_true", help="RT_FLAG_F32_ONLY: without the f64 chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the C4 / cover-image 4K frames")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -104,56 +124,122 @@ def cpu_baseline(name: str, width: int, height: int, jitter: int, seed: int, tar
     }, st
 
 
-def traffic_from_profile(args, world):
-    """HBM bytes per launch of the render kernel, measured with PMC counters in their own runs
-    (scripts/traffic.sh) and committed as profiles/traffic.json — valid for the default workload on
-    one GPU only; anything else reports null."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    default = args.workload == "striped_sphere_multiple_lights" and not args.width and not args.height and \
-        args.jitter == "counter" and args.seed == 0
-    if world != 1 or not default or not os.path.exists(path):
+def pmc_of(workload: str, kernel: str):
+    """Per-launch hardware counters of this workload's kernel, collected in their own rocprofv3 --pmc runs
+    (scripts/roofline_pmc.sh, merged into profiles/pmc.json) — valid for the config's full frame on one GPU."""
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+        table = json.load(f).get(workload, {})
+    for k, v in table.items():
+        if kernel in k:
+            return v
+    return None
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-        sys.exit(2)
-    rehearsal = os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctl = torch.device("cpu") if rehearsal else dev  # where the control-plane tensors live
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
+def hardware_roofline(pmc: dict | None, kernel_ms: float) -> dict:
+    """Executed FP32 flop/s and issue statistics from the committed counters and the live kernel time."""
+    if not pmc:
+        return {"executed_tflops": None, "frac": None, "valu_issue_frac": None, "waves_per_simd": None, "wait_frac": None,
+                "lane_util": None, "traffic": None, "counters": "no PMC run of this workload/kernel in profiles/pmc.json"}
+    g = pmc.get
+    f32 = g("SQ_INSTS_VALU_ADD_F32", 0) + g("SQ_INSTS_VALU_MUL_F32", 0) + 2 * g("SQ_INSTS_VALU_FMA_F32", 0) + g("SQ_INSTS_VALU_TRANS_F32", 0)
+    f64 = g("SQ_INSTS_VALU_ADD_F64", 0) + g("SQ_INSTS_VALU_MUL_F64", 0) + 2 * g("SQ_INSTS_VALU_FMA_F64", 0) + g("SQ_INSTS_VALU_TRANS_F64", 0)
+    sec = kernel_ms * 1e-3
+    executed = 64.0 * f32 / sec / 1e12  # every counted instruction a full wave: an upper bound on executed FP32
+    out = {
+        "executed_tflops": executed, "frac": executed / flopmodel.PEAK_FP32_TFLOPS,
+        "executed_f64_tflops": 64.0 * f64 / sec / 1e12,
+        # wave-instructions issued on the vector pipes over what the chip can issue (one wave64 op per 2 cycles per SIMD)
+        "valu_issue_frac": g("SQ_INSTS_VALU", 0) / sec / flopmodel.PEAK_VALU_WAVE_INSTS_PER_S,
+        "fp32_share_of_valu": (g("SQ_INSTS_VALU_ADD_F32", 0) + g("SQ_INSTS_VALU_MUL_F32", 0) + g("SQ_INSTS_VALU_FMA_F32", 0) +
+                               g("SQ_INSTS_VALU_TRANS_F32", 0)) / max(1.0, g("SQ_INSTS_VALU", 0)),
+        # SQ_WAVE_CYCLES counts quad-cycles summed over waves; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
+        "waves_per_simd": 4.0 * g("SQ_WAVE_CYCLES", 0) / (g("GRBM_GUI_ACTIVE", 1) / 8.0) / (N_CU * N_SIMD) if g("GRBM_GUI_ACTIVE") else None,
+        "wait_frac": g("SQ_WAIT_ANY", 0) / g("SQ_WAVE_CYCLES", 1) if g("SQ_WAVE_CYCLES") else None,
+        "lane_util": g("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * g("SQ_ACTIVE_INST_VALU", 1)) if g("SQ_ACTIVE_INST_VALU") else None,
+        # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE doubled per the gfx950 correction
+        "traffic": int(1024 * (2 * g("FETCH_SIZE", 0) + g("WRITE_SIZE", 0))) if g("WRITE_SIZE") else None,
+        "counters": "profiles/pmc.json (rocprofv3 --pmc, scripts/roofline_pmc.sh), per launch; kernel time measured live",
+    }
+    return out
 
-        dist = dist_mod
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
 
-    width, height = WORKLOADS[args.workload]
-    width, height = args.width or width, args.height or height
-    ex = ExampleScene(args.workload, width, height)
-    scene = Scene(ex.scene_desc, local_rank)
+class Job:
+    """Process-wide state of one bench run: ranks, devices, control plane."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus != self.world and self.world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+        self.rehearsal = os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1"
+        if self.rehearsal:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.ctl = torch.device("cpu") if self.rehearsal else self.dev  # where the control-plane tensors live
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist_mod
+
+            self.dist = dist_mod
+            if self.rehearsal:
+                self.dist.init_process_group(backend="gloo")
+            else:
+                self.dist.init_process_group(backend="nccl", device_id=self.dev)
+        self.hip = None
+        try:
+            self.hip = C.CDLL("libamdhip64.so")
+            self.hip.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                                  C.c_void_p]
+            self.hip.hipMemcpy2DAsync.restype = C.c_int
+            self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            self.hip.hipMemset.restype = C.c_int
+        except (OSError, AttributeError):
+            self.hip = None
+
+    def sync_all(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def agree(self, ok: bool) -> bool:
+        """True iff every rank says ok (the same collective on every rank, whatever happened locally)."""
+        if self.world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.ctl)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.ctl)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmup: int, sustain_s: float) -> dict:
+    """Times `steps` frames of one workload on this job's partition; returns rank 0's report."""
+    args, rank, world, dist = job.args, job.rank, job.world, job.dist
+    ex = ExampleScene(name, width, height)
+    scene = Scene(ex.scene_desc, job.local_rank)
     n_lights = int(ex.scene_desc.contents.n_lights)
 
     base = RtOptions()
     base.jitter_mode = 1 if args.jitter == "counter" else 0
     base.seed = args.seed
+    base.flags = 2 if args.f32_only else 0
     opt = partition.rank_options(base, rank, world)
     max_rows = partition.padded_rows(height, world)
     assert scene.output_rows(ex.camera_desc, opt) <= max_rows
-    local = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
+    local = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=job.dev)
 
     # Frame assembly for N > 1: one shared frame in rank 0's HBM, or the gather fallback.
     shared = None
@@ -163,23 +249,19 @@ def main():
         box = [None, None]
         if rank == 0:
             try:
-                shared = SharedFrame(height, width, local_rank)
-                box = [shared.handle, local_rank]
+                shared = SharedFrame(height, width, job.local_rank)
+                box = [shared.handle, job.local_rank]
             except Exception as e:  # noqa: BLE001 - any failure means: use the gather path
                 print(f"bench.py: shared frame not available on rank 0 ({e})", file=sys.stderr)
         dist.broadcast_object_list(box, src=0)
-        ok = 1
-        if box[0] is None:
-            ok = 0
-        elif rank != 0:
+        ok = box[0] is not None
+        if ok and rank != 0:
             try:
-                shared = SharedFrame(height, width, local_rank, owner_device=box[1], handle=box[0])
+                shared = SharedFrame(height, width, job.local_rank, owner_device=box[1], handle=box[0])
             except Exception as e:  # noqa: BLE001
                 print(f"bench.py: rank {rank} cannot map the shared frame ({e})", file=sys.stderr)
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+                ok = False
+        if not job.agree(ok):
             mode = "gather"
             if shared is not None:
                 shared.close()
@@ -187,96 +269,82 @@ def main():
     opt_frame = opt
     if mode == "p2p":
         opt_frame = partition.rank_options(base, rank, world)
-        opt_frame.flags = RT_FLAG_GLOBAL_ROWS
+        opt_frame.flags = base.flags | RT_FLAG_GLOBAL_ROWS
     final = perm = gathered = None
     if mode == "gather" and rank == 0:
         gathered = [torch.empty_like(local) for _ in range(world)]
-        perm = torch.from_numpy(partition.gather_permutation(height, world)).to(dev)
-        final = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+        perm = torch.from_numpy(partition.gather_permutation(height, world)).to(job.dev)
+        final = torch.empty((height, width, 3), dtype=torch.float32, device=job.dev)
 
-    hip = None
-    if mode == "p2p":
-        try:
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
-                                             C.c_void_p]
-            hip.hipMemcpy2DAsync.restype = C.c_int
-        except (OSError, AttributeError):
-            hip = None
     my_rows = int(scene.output_rows(ex.camera_desc, opt))
+
     def move_bands(stream):
         """This rank's packed bands -> their rows of the shared frame: one strided copy (+ a last partial band)."""
         for dst, dpitch, src, spitch, wbytes, rows in partition.band_copy_plan(width, rank, world, my_rows):
-            rc = hip.hipMemcpy2DAsync(shared.ptr.value + dst, dpitch, local.data_ptr() + src, spitch, wbytes, rows, 4, stream)
+            rc = job.hip.hipMemcpy2DAsync(shared.ptr.value + dst, dpitch, local.data_ptr() + src, spitch, wbytes, rows, 4, stream)
             if rc != 0:
                 raise RuntimeError(f"hipMemcpy2DAsync failed ({rc})")
 
-    def frame():
+    def frame(m):
         stream = torch.cuda.current_stream().cuda_stream
-        if mode == "p2p":
+        if m == "p2p":
             scene.render_device(ex.camera_desc, shared.ptr.value, opt_frame, stream)
             return
         scene.render_device(ex.camera_desc, local.data_ptr(), opt, stream)
-        if mode == "copy2d":
+        if m == "copy2d":
             move_bands(stream)
-        if mode == "gather":
+        if m == "gather":
             dist.gather(local, gathered, dst=0)
             if rank == 0:
                 torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     # ray / work counters of this rank's share (untimed, instrumented kernel variant)
     _, st = scene.render(ex.camera_desc, opt, stats=True)
-    counts = torch.tensor([st.primary_rays, st.reflection_rays, st.refraction_rays, st.shadow_rays, st.shaded_hits,
-                           st.light_cells, st.pattern_lookups, st.container_passes], dtype=torch.int64, device=ctl)
+    mine = {k: int(getattr(st, k)) for k in COUNTER_NAMES}
+    counts = torch.tensor([mine[k] for k in COUNTER_NAMES], dtype=torch.int64, device=job.ctl)
     if world > 1:
         dist.all_reduce(counts)
-    names = ["primary_rays", "reflection_rays", "refraction_rays", "shadow_rays", "shaded_hits", "light_cells",
-             "pattern_lookups", "container_passes"]
-    total = dict(zip(names, (int(v) for v in counts.tolist())))
-    mine = dict(zip(names, (st.primary_rays, st.reflection_rays, st.refraction_rays, st.shadow_rays, st.shaded_hits,
-                            st.light_cells, st.pattern_lookups, st.container_passes)))
+    total = dict(zip(COUNTER_NAMES, (int(v) for v in counts.tolist())))
     total_rays = total["primary_rays"] + total["reflection_rays"] + total["refraction_rays"] + total["shadow_rays"]
+    rays_cast = total["primary_rays"] + total["reflection_rays"] + total["refraction_rays"] + total["shadow_rays_cast"]
 
-    # direct stores or one strided copy per rank?  A few untimed frames of each; every rank takes the
-    # same decision because it is taken on the all-reduced times.
+    # direct stores or one strided copy per rank?  A few untimed frames of each; every rank runs the SAME
+    # sequence of barriers and collectives whatever happens locally, and takes the same decision (it is taken
+    # on the all-reduced times).
     calibration = None
-    if mode == "p2p" and hip is not None:
+    if mode == "p2p" and job.hip is not None:
         took = {}
         for m in ("p2p", "copy2d"):
-            mode = m
-            ok = 1
+            ok, t0 = True, 0.0
             try:
-                frame()
-                sync_all()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    frame()
-                sync_all()
-                took[m] = time.perf_counter() - t0
+                frame(m)
             except RuntimeError as e:
                 print(f"bench.py: rank {rank}: {m} not usable ({e})", file=sys.stderr)
-                ok, took[m] = 0, float("inf")
-            flag = torch.tensor([took[m] if ok else 1e30], dtype=torch.float64, device=ctl)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            took[m] = float(flag.item())
+                ok = False
+            job.sync_all()
+            t0 = time.perf_counter()
+            if ok:
+                try:
+                    for _ in range(5):
+                        frame(m)
+                except RuntimeError as e:
+                    print(f"bench.py: rank {rank}: {m} failed ({e})", file=sys.stderr)
+                    ok = False
+            job.sync_all()
+            dt = time.perf_counter() - t0
+            took[m] = job.max_over_ranks(dt if ok else 1e30)
         mode = "copy2d" if took["copy2d"] < took["p2p"] else "p2p"
         forced = os.environ.get("RT_BENCH_ASSEMBLY")  # "p2p" / "copy2d": skip the choice (rehearsals)
         if forced in took and took[forced] < 1e29:
             mode = forced
         calibration = {k: (v / 5 * 1e3 if v < 1e29 else None) for k, v in took.items()}
 
-    for _ in range(args.warmup):
-        frame()
-    sync_all()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(warmup):
+        frame(mode)
+    job.sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         stream = torch.cuda.current_stream().cuda_stream
         ev[k][0].record()
         if mode == "p2p":
@@ -290,78 +358,146 @@ def main():
             dist.gather(local, gathered, dst=0)
             if rank == 0:
                 torch.index_select(torch.cat(gathered, 0), 0, perm, out=final)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    job.sync_all()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel
 
-    # the assembled frame must be the frame one GPU renders alone, bit for bit (untimed check)
-    verified = None
-    if world > 1 and rank == 0:
-        whole, _ = scene.render(ex.camera_desc, base)
-        got = shared.download() if mode in ("p2p", "copy2d") else final.cpu().numpy()
-        verified = bool(np.array_equal(whole, got))
+    # sustained: back-to-back frames for >= sustain_s (every rank runs the same count)
+    sustained = None
+    if sustain_s > 0:
+        n = max(steps, int(math.ceil(sustain_s / max(elapsed / steps, 1e-6))))
+        job.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            frame(mode)
+        job.sync_all()
+        dt = job.max_over_ranks(time.perf_counter() - t0)
+        sustained = {"frames": n, "seconds": dt, "ms_per_frame": dt * 1e3 / n}
 
+    # The assembled frame must be the frame one GPU renders alone, bit for bit (untimed).  The frame is first
+    # filled with a sentinel, then ONE frame is rendered in the chosen mode: stale contents cannot pass.
+    verified = None
+    if world > 1:
+        job.sync_all()
+        if rank == 0:
+            if mode in ("p2p", "copy2d"):
+                if job.hip is None or job.hip.hipMemset(shared.ptr, 0xFF, shared.nbytes) != 0:
+                    print("bench.py: could not fill the shared frame with the sentinel", file=sys.stderr)
+            else:
+                final.fill_(float("nan"))
+        job.sync_all()
+        frame(mode)
+        job.sync_all()
+        if rank == 0:
+            whole, _ = scene.render(ex.camera_desc, base)
+            got = shared.download() if mode in ("p2p", "copy2d") else final.cpu().numpy()
+            verified = bool(np.array_equal(whole, got))
+
+    rep = None
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
+        ms = elapsed * 1e3 / steps
+        rep = {
+            "workload": f"examples/{name} at {width}x{height}, jitter={args.jitter} seed={args.seed}, RECURSION_DEPTH=5, "
+                        f"{'FP32 only' if args.f32_only else 'f64 chain on'}",
+            "frame_ms": ms, "kernel_ms": kernel_ms, "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
+            "assembled_frame_equals_single_gpu_frame": verified, "sustained": sustained,
+            "rays_per_frame": total_rays, "rays_cast": rays_cast, "cast_share": rays_cast / max(1, total_rays),
+            "rays_by_kind": total, "mrays_per_s": total_rays / (ms * 1e-3) / 1e6, "mrays_cast_per_s": rays_cast / (ms * 1e-3) / 1e6,
+            "kernel": scene.kernel_name(ex.camera_desc, opt), "mine": mine, "n_lights": n_lights,
+            "rows_of_rank0": my_rows, "scene_desc": ex.scene_desc,
+        }
+    if world > 1:
+        job.sync_all()
+        if shared is not None and rank != 0:
+            shared.close()
+        dist.barrier()
+        if shared is not None and rank == 0:
+            shared.close()
+    scene.close()
+    return rep
+
+
+def main():
+    args = parse_args()
+    job = Job(args)
+    world = job.world
+    width, height = WORKLOADS[args.workload]
+    width, height = args.width or width, args.height or height
+    head = run_workload(job, args.workload, width, height, args.steps, args.warmup, sustain_s=0.3)
+
+    also = {}
+    if not args.no_also:
+        for name in ALSO:
+            if name == args.workload:
+                continue
+            w, h = WORKLOADS[name]
+            r = run_workload(job, name, w, h, steps=5, warmup=1, sustain_s=0.0)
+            if r is not None:
+                also[name] = {k: r[k] for k in ("workload", "frame_ms", "kernel_ms", "assembly", "assembled_frame_equals_single_gpu_frame",
+                                                "rays_per_frame", "rays_cast", "mrays_per_s", "mrays_cast_per_s", "kernel")}
+
+    if job.rank == 0:
+        opt_jitter = 1 if args.jitter == "counter" else 0
         cpu, ost = (None, None)
         if world == 1 and not args.no_cpu_baseline:
-            cpu, ost = cpu_baseline(args.workload, width, height, opt.jitter_mode, opt.seed, args.cpu_seconds)
-        cost = flopmodel.ray_cost(ex.scene_desc, ost)
-        flops = flopmodel.frame_flops(mine, n_lights, cost)  # rank 0's launch
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
+            cpu, ost = cpu_baseline(args.workload, width, height, opt_jitter, args.seed, args.cpu_seconds)
+        cost = flopmodel.ray_cost(head["scene_desc"], ost)
+        flops = flopmodel.frame_flops(head["mine"], head["n_lights"], cost)  # rank 0's launch
+        kernel_ms = head["kernel_ms"]
+        ref_equiv = flops / (kernel_ms * 1e-3) / 1e12
+        default_frame = world == 1 and not args.width and not args.height and args.jitter == "counter" and args.seed == 0
+        hw = hardware_roofline(pmc_of(args.workload, head["kernel"]) if default_frame else None, kernel_ms)
         out = {
             "metric": "Mrays/sec (primary+secondary) and frame ms at 1080p/4K, 1 and 8 MI355X",
-            "value": total_rays / (ms_per_step * 1e-3) / 1e6,
+            "value": head["mrays_per_s"],
             "unit": "Mrays/s",
+            "value_counts": "reference-equivalent rays (every ray of the reference's accounting; see config.rays_cast)",
+            "value_cast": head["mrays_cast_per_s"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": head["frame_ms"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"examples/{args.workload} at {width}x{height}, jitter={args.jitter} seed={args.seed}, "
-                            f"RECURSION_DEPTH=5",
+                "workload": head["workload"],
                 "partition": "whole frame on one GPU" if world == 1 else (
                     f"interleaved {BAND_ROWS}-row bands over {world} GPUs, every rank's kernel stores its rows straight "
-                    f"into ONE frame in rank 0's HBM (peer access over xGMI, no collective)" if mode == "p2p" else
+                    f"into ONE frame in rank 0's HBM (peer access over xGMI, no collective)" if head["assembly"] == "p2p" else
                     f"interleaved {BAND_ROWS}-row bands over {world} GPUs, every rank moves its bands with one strided "
                     f"device-to-device copy into ONE frame in rank 0's HBM (peer access over xGMI, no collective)"
-                    if mode == "copy2d" else
+                    if head["assembly"] == "copy2d" else
                     f"interleaved {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"),
-                "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
-                "assembled_frame_equals_single_gpu_frame": verified,
-                "rays_per_frame": total_rays, "rays_by_kind": total,
+                "assembly": head["assembly"], "assembly_calibration_ms_per_frame": head["assembly_calibration_ms_per_frame"],
+                "assembled_frame_equals_single_gpu_frame": head["assembled_frame_equals_single_gpu_frame"],
+                "rays_per_frame": head["rays_per_frame"], "rays_cast": head["rays_cast"], "cast_share": head["cast_share"],
+                "rays_by_kind": head["rays_by_kind"],
             },
-            "frame_ms": ms_per_step,
+            "frame_ms": head["frame_ms"],
             "kernel_ms": kernel_ms,
+            "sustained": head["sustained"],
             "roofline": {
-                "bound": "valu_fp32", "achieved": achieved, "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / flopmodel.PEAK_FP32_TFLOPS,
-                # HBM bytes per launch come from SEPARATE rocprofv3 --pmc runs of this same command
-                # (scripts/traffic.sh -> profiles/traffic.json, default workload only); null otherwise
-                "traffic": traffic_from_profile(args, world),
-                "algorithmic_hbm_bytes_per_launch": int(scene.output_rows(ex.camera_desc, opt)) * width * 12,
-                "algorithmic_flop_per_launch": flops, "flop_per_ray_intersection": cost,
-                "kernel": "render_kernel<false, false, false, true>", "kernel_ms": kernel_ms,
+                "bound": "valu_fp32", "achieved": hw["executed_tflops"], "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": hw["frac"], "traffic": hw["traffic"],
+                "executed_tflops": hw["executed_tflops"], "executed_f64_tflops": hw.get("executed_f64_tflops"),
+                "valu_issue_frac": hw["valu_issue_frac"], "fp32_share_of_valu": hw.get("fp32_share_of_valu"),
+                "waves_per_simd": hw["waves_per_simd"], "wait_frac": hw["wait_frac"], "lane_util": hw["lane_util"],
+                "counters": hw["counters"],
+                "reference_equivalent": {"tflops": ref_equiv, "frac_of_peak": ref_equiv / flopmodel.PEAK_FP32_TFLOPS,
+                                         "flop_per_launch": flops, "flop_per_ray_intersection": cost,
+                                         "note": "the REFERENCE algorithm's flop for this frame over the kernel time: credit for "
+                                                 "avoided work (culling, shadow rays answered without casting), not a hardware fraction"},
+                "algorithmic_hbm_bytes_per_launch": head["rows_of_rank0"] * width * 12,
+                "kernel": head["kernel"], "kernel_ms": kernel_ms,
             },
+            "also": also,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
-        sync_all()
-        if shared is not None and rank != 0:
-            shared.close()
-        dist.barrier()
-        if shared is not None and rank == 0:
-            shared.close()
-        dist.destroy_process_group()
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

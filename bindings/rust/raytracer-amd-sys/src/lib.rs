@@ -104,6 +104,7 @@ extern "C" {
     pub fn rt_device_count(count_out: *mut c_int) -> c_int;
     pub fn rt_scene_create(desc: *const rt_scene_desc, device: c_int, scene_out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
+    pub fn rt_scene_variant(scene: *const rt_scene, flags_out: *mut u32) -> c_int;
     pub fn rt_output_rows(camera: *const rt_camera_desc, options: *const rt_options, rows_out: *mut u32) -> c_int;
     pub fn rt_render_device(
         scene: *mut rt_scene,

@@ -79,7 +79,7 @@ class RtStats(C.Structure):
 
 # Every symbol include/rt_amd.h declares (tests check that the library exports all of them).
 RT_SYMBOLS = [
-    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
+    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_variant",
     "rt_output_rows", "rt_render_device", "rt_render", "rt_render_stats", "rt_render_stats_noalloc", "rt_quantize_u8_device",
     "rt_quantize_u8", "rt_frame_create", "rt_frame_open", "rt_frame_close", "rt_frame_destroy", "rt_frame_download",
 ]
@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
         L.rt_scene_create.argtypes = [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_scene_destroy.restype = None
+        L.rt_scene_variant.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.rt_output_rows.argtypes = [C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.POINTER(C.c_uint32)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
@@ -194,6 +195,15 @@ class Scene:
         self._h = C.c_void_p()
         self.device = device
         _check(lib().rt_scene_create(scene_desc, device, C.byref(self._h)))
+
+    def kernel_name(self, camera_desc, options: Optional[RtOptions] = None, stats: bool = False) -> str:
+        """Name of the render kernel instantiation a call with this camera and these options launches."""
+        v = C.c_uint32()
+        _check(lib().rt_scene_variant(self._h, C.byref(v)))
+        cam = camera_desc.contents if hasattr(camera_desc, "contents") else camera_desc
+        f64 = bool(v.value & 8) and bool(cam.has_f64) and not (options is not None and options.flags & RT_FLAG_F32_ONLY)
+        b = lambda x: "true" if x else "false"  # noqa: E731
+        return f"render_kernel<{b(stats)}, {b(v.value & 4)}, {b(v.value & 2)}, {b(v.value & 1)}, {b(f64)}>"
 
     def output_rows(self, camera_desc, options: Optional[RtOptions] = None) -> int:
         rows = C.c_uint32()

@@ -298,6 +298,13 @@ void rt_scene_destroy(rt_scene* s) {
     delete s;
 }
 
+int rt_scene_variant(const rt_scene* s, uint32_t* flags_out) {
+    if (!s || !flags_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_variant: null argument");
+    *flags_out = (s->area ? RT_VARIANT_AREA : 0u) | (s->tree ? RT_VARIANT_TREE : 0u) | (s->exotic ? RT_VARIANT_EXOTIC : 0u) |
+                 (s->has_f64 ? RT_VARIANT_F64 : 0u);
+    return RT_OK;
+}
+
 int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint32_t* rows_out) {
     if (!rows_out) return fail(RT_ERR_BAD_ARGUMENT, "rows_out is null");
     RenderPlan rp{};

@@ -519,7 +519,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const DPrim p = sc.recs[hit_prim];
             mi = p.material;
             const DMaterial m = sc.mats[mi];
-            const HitInfo h = prepare_hit<EXOTIC>(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v);
+            const bool patterned = EXACT && sc.pats[m.pattern].type != PAT_SOLID;  // (else h.eq is not needed)
+            const HitInfo h = prepare_hit<EXOTIC>(p, sc.extras, cur, cur.self == hit_prim, hit_t, hit_u, hit_v, patterned);
             over = h.p + h.n * kEps, nrm = h.n, hq = h.q, hdq = h.dq, hit_inside = h.inside;
             pc = pattern_color(sc.pats[m.pattern], h.q + h.dq);  // pattern at over_point (material.rs:127)
             // EXACT: a pattern lookup within FP32 reach of a boundary, or a local normal that was a near

@@ -791,13 +791,15 @@ struct HitInfo {
 };
 
 template <bool EXOTIC = true>
-RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, float t, float hu, float hv) {
+RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, float t, float hu, float hv,
+                          bool want_eq = true) {  // want_eq = false: h.eq is not needed (solid pattern, FP32-only path)
     HitInfo h;
     V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
     if (self) o = ray.q + ray.dq;
     V3 q = madd(d, t, o);
     V3 nobj = v3(0.0f, 1.0f, 0.0f);
-    {  // (a coordinate the snap below makes exact carries no error: the height over a plane, a cube's face)
+    h.eq = v3(0.0f, 0.0f, 0.0f);
+    if (want_eq) {  // (a coordinate the snap below makes exact carries no error: the height over a plane, a cube's face)
         const float e = 3e-7f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(t) * (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) + 1.0f);
         h.eq = v3(e, e, e);
     }
@@ -813,7 +815,7 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
         }
         case PRIM_PLANE:  // plane.rs:53-55
             q.y = 0.0f;
-            {  // t = -o.y / d.y is ill-conditioned for a grazing ray: its error moves the point along the ray
+            if (want_eq) {  // t = -o.y / d.y is ill-conditioned for a grazing ray: its error moves the point along the ray
                 const float a = fabsf(p.inv[4] * ray.o.x) + fabsf(p.inv[5] * ray.o.y) + fabsf(p.inv[6] * ray.o.z) + fabsf(p.inv[7]);
                 const float b = fabsf(p.inv[4] * ray.d.x) + fabsf(p.inv[5] * ray.d.y) + fabsf(p.inv[6] * ray.d.z);
                 const float dt = 2e-7f * fmaf(fabsf(t), b, a) * rcp_f(fabsf(d.y));
