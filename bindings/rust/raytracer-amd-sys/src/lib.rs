@@ -1,12 +1,19 @@
 //! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 2).  What `bindgen` would emit, written
 //! by hand because the header is small and stable.  UNVERIFIED: no Rust toolchain exists in the
 //! environment this was written in; the C++ mirror of the same calls is what is compiled and tested.
+//! `tests/test_rust_binding.py` parses this file and the header and compares every function (argument
+//! names, order, types), struct field, constant and enum value, so the two cannot drift apart unnoticed.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RT_ABI_VERSION: u32 = 2;
 pub const RT_ITEM_NODE: u32 = 0x8000_0000;
 pub const RT_OK: c_int = 0;
+pub const RT_ERR_BAD_ARGUMENT: c_int = -1;
+pub const RT_ERR_UNSUPPORTED: c_int = -2;
+pub const RT_ERR_CAPACITY: c_int = -3;
+pub const RT_ERR_HIP: c_int = -4;
+pub const RT_ERR_NO_DEVICE: c_int = -5;
 
 pub const RT_PRIM_SPHERE: u8 = 0;
 pub const RT_PRIM_PLANE: u8 = 1;
@@ -54,6 +61,11 @@ pub struct rt_scene_desc {
     pub light_usteps: *const u32,
     pub light_vsteps: *const u32,
     pub light_color: *const f32,
+    // optional f64 tables: all four or none (null)
+    pub prim_inv64: *const f64,
+    pub prim_param64: *const f64,
+    pub mat_ior64: *const f64,
+    pub pat_inv64: *const f64,
 }
 
 #[repr(C)]
@@ -65,6 +77,11 @@ pub struct rt_camera_desc {
     pub half_width: f32,
     pub half_height: f32,
     pub inv: [f32; 12],
+    pub has_f64: u32,
+    pub pixel_size64: f64,
+    pub half_width64: f64,
+    pub half_height64: f64,
+    pub inv64: [f64; 12],
 }
 
 #[repr(C)]
@@ -148,6 +165,14 @@ extern "C" {
 }
 
 pub const RT_FLAG_GLOBAL_ROWS: u32 = 1;
+pub const RT_FLAG_F32_ONLY: u32 = 2;
+pub const RT_VARIANT_AREA: u32 = 1;
+pub const RT_VARIANT_TREE: u32 = 2;
+pub const RT_VARIANT_EXOTIC: u32 = 4;
+pub const RT_VARIANT_F64: u32 = 8;
+pub const RT_MAX_DEPTH: u32 = 8;
+pub const RT_MAX_LIGHTS: u32 = 256;
+pub const RT_MAX_LIGHT_CELLS: u32 = 32768;
 pub const RT_NOALLOC_MAX_TILES: u32 = 131072;
 
 #[repr(C)]

@@ -60,6 +60,12 @@ pub(crate) struct FlatScene {
     light_usteps: Vec<u32>,
     light_vsteps: Vec<u32>,
     light_color: Vec<f32>,
+    // the same tables in the crate's own f64 (rt_scene_desc.*64): the kernels work the hits that decide
+    // something out again with these, so pattern boundaries and silhouettes follow this crate's arithmetic
+    prim_inv64: Vec<f64>,
+    prim_param64: Vec<f64>,
+    mat_ior64: Vec<f64>,
+    pat_inv64: Vec<f64>,
 }
 
 /// First three rows of an affine 4x4, row-major, f64 -> f32 (rounded once).
@@ -69,6 +75,18 @@ pub(crate) fn rows3x4(t: &Transform) -> [f32; 12] {
     for r in 0..3 {
         for c in 0..4 {
             out[4 * r + c] = m[r][c] as f32;
+        }
+    }
+    out
+}
+
+/// The same rows, unrounded.
+pub(crate) fn rows3x4_f64(t: &Transform) -> [f64; 12] {
+    let m = &t.0 .0;
+    let mut out = [0f64; 12];
+    for r in 0..3 {
+        for c in 0..4 {
+            out[4 * r + c] = m[r][c];
         }
     }
     out
@@ -106,6 +124,7 @@ impl FlatScene {
         push_color(&mut self.pat_color_a, a);
         push_color(&mut self.pat_color_b, b);
         self.pat_inv.extend_from_slice(&rows3x4(&inv));
+        self.pat_inv64.extend_from_slice(&rows3x4_f64(&inv));
         self.patterns.push(pattern.clone());
         (self.patterns.len() - 1) as u32
     }
@@ -126,6 +145,7 @@ impl FlatScene {
             0.0,
         ]);
         self.mat_pattern.push(pattern);
+        self.mat_ior64.push(material.index_of_refraction);
         self.materials.push(material.clone());
         (self.materials.len() - 1) as u32
     }
@@ -147,14 +167,14 @@ impl FlatScene {
             return;
         }
         let cache: &crate::shape::ObjectCache = shape.as_ref();
-        let mut param = [0f32; 24];
+        let mut param = [0f64; 24]; // filled in f64, rounded once for the f32 table
         let tag = match shape {
             Shape::Sphere(_) => sys::RT_PRIM_SPHERE,
             Shape::Plane(_) => sys::RT_PRIM_PLANE,
             Shape::Cube(_) => sys::RT_PRIM_CUBE,
             Shape::Cylinder(c) => {
-                param[0] = c.min as f32;
-                param[1] = c.max as f32;
+                param[0] = c.min;
+                param[1] = c.max;
                 param[2] = if c.closed { 1.0 } else { 0.0 };
                 sys::RT_PRIM_CYLINDER
             }
@@ -165,9 +185,9 @@ impl FlatScene {
             Shape::SmoothTriangle(s) => {
                 fill_triangle(&mut param, &s.triangle);
                 for (k, n) in [s.n0, s.n1, s.n2].iter().enumerate() {
-                    param[12 + 3 * k] = n.0.x as f32;
-                    param[13 + 3 * k] = n.0.y as f32;
-                    param[14 + 3 * k] = n.0.z as f32;
+                    param[12 + 3 * k] = n.0.x;
+                    param[13 + 3 * k] = n.0.y;
+                    param[14 + 3 * k] = n.0.z;
                 }
                 sys::RT_PRIM_SMOOTH_TRIANGLE
             }
@@ -178,7 +198,9 @@ impl FlatScene {
         self.prim_type.push(tag);
         self.prim_inv.extend_from_slice(&rows3x4(&cache.transform_inverse));
         self.prim_material.push(material);
-        self.prim_param.extend_from_slice(&param);
+        self.prim_inv64.extend_from_slice(&rows3x4_f64(&cache.transform_inverse));
+        self.prim_param.extend(param.iter().map(|v| *v as f32));
+        self.prim_param64.extend_from_slice(&param);
         self.item_ref.push(prim);
         self.item_next.push(self.item_ref.len() as u32);
     }
@@ -237,16 +259,20 @@ impl FlatScene {
             light_usteps: self.light_usteps.as_ptr(),
             light_vsteps: self.light_vsteps.as_ptr(),
             light_color: self.light_color.as_ptr(),
+            prim_inv64: self.prim_inv64.as_ptr(),
+            prim_param64: self.prim_param64.as_ptr(),
+            mat_ior64: self.mat_ior64.as_ptr(),
+            pat_inv64: self.pat_inv64.as_ptr(),
         }
     }
 }
 
-fn fill_triangle(param: &mut [f32; 24], t: &crate::shape::Triangle) {
+fn fill_triangle(param: &mut [f64; 24], t: &crate::shape::Triangle) {
     let fields = [t.v0.0, t.e0.0, t.e1.0, t.normal.0];
     for (k, v) in fields.iter().enumerate() {
-        param[3 * k] = v.x as f32;
-        param[3 * k + 1] = v.y as f32;
-        param[3 * k + 2] = v.z as f32;
+        param[3 * k] = v.x;
+        param[3 * k + 1] = v.y;
+        param[3 * k + 2] = v.z;
     }
 }
 
@@ -275,6 +301,11 @@ pub(crate) fn render(camera: &Camera, world: &World) -> Canvas {
         half_width: camera.half_width as f32,
         half_height: camera.half_height as f32,
         inv: rows3x4(&camera.transform_inverse),
+        has_f64: 1,
+        pixel_size64: camera.pixel_size,
+        half_width64: camera.half_width,
+        half_height64: camera.half_height,
+        inv64: rows3x4_f64(&camera.transform_inverse),
     };
     let options = sys::rt_options {
         jitter_mode: sys::RT_JITTER_COUNTER,
