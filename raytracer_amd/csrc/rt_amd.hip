@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -124,6 +125,7 @@ struct rt_scene {
     NoAllocScratch* scratch_ptr = nullptr;  // this device's copy of `scratch` (rt_render_stats_noalloc)
     bool exotic = false;  // some primitive is a cylinder or a triangle
     bool tree = false;    // the stream has hierarchy nodes or Group gates
+    bool lane = false;    // a hierarchy long enough for lane-mode walks (rt_kernel.h LANE)
     bool area = false;    // some light is an area light
     bool has_f64 = false; // the caller gave the f64 tables of the exact chain (rt_exact.h)
     KScene k{};
@@ -157,21 +159,30 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     if (P.n_tiles == 0) return RT_OK;
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
-    // 32 instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
+    // 48 instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
+    // (x lane-mode walks for the hierarchy variants)
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
-#define RT_KERNELS(X)                                                                                      \
-    {render_kernel<false, false, false, false, X>, render_kernel<false, false, false, true, X>,           \
-     render_kernel<false, false, true, false, X>,  render_kernel<false, false, true, true, X>,            \
-     render_kernel<false, true, false, false, X>,  render_kernel<false, true, false, true, X>,            \
-     render_kernel<false, true, true, false, X>,   render_kernel<false, true, true, true, X>,             \
-     render_kernel<true, false, false, false, X>,  render_kernel<true, false, false, true, X>,            \
-     render_kernel<true, false, true, false, X>,   render_kernel<true, false, true, true, X>,             \
-     render_kernel<true, true, false, false, X>,   render_kernel<true, true, false, true, X>,             \
-     render_kernel<true, true, true, false, X>,    render_kernel<true, true, true, true, X>}
-    void (*const kernels_f32[16])(const KParams) = RT_KERNELS(false);
-    void (*const kernels_f64[16])(const KParams) = RT_KERNELS(true);
+// (timing experiments on ONE family, scripts/exp_build.sh: -DRT_EXP_ONLY_TREE compiles the plain hierarchy kernels only)
+#ifdef RT_EXP_ONLY_TREE
+#define RT_K(S, E, T, A, X, L) render_kernel<S, false, true, false, X, L>
+#else
+#define RT_K(S, E, T, A, X, L) render_kernel<S, E, T, A, X, (T) && (L)>
+#endif
+#define RT_KERNELS(X, L)                                                                                         \
+    {RT_K(false, false, false, false, X, L), RT_K(false, false, false, true, X, L),                              \
+     RT_K(false, false, true, false, X, L),  RT_K(false, false, true, true, X, L),                               \
+     RT_K(false, true, false, false, X, L),  RT_K(false, true, false, true, X, L),                               \
+     RT_K(false, true, true, false, X, L),   RT_K(false, true, true, true, X, L),                                \
+     RT_K(true, false, false, false, X, L),  RT_K(true, false, false, true, X, L),                               \
+     RT_K(true, false, true, false, X, L),   RT_K(true, false, true, true, X, L),                                \
+     RT_K(true, true, false, false, X, L),   RT_K(true, true, false, true, X, L),                                \
+     RT_K(true, true, true, false, X, L),    RT_K(true, true, true, true, X, L)}
+    // [f64 chain][lane mode][variant]; lane mode only exists for the hierarchy variants (the others repeat the union kernels)
+    void (*const kernels[2][2][16])(const KParams) = {{RT_KERNELS(false, false), RT_KERNELS(false, true)},
+                                                      {RT_KERNELS(true, false), RT_KERNELS(true, true)}};
 #undef RT_KERNELS
-    hipLaunchKernelGGL((exact ? kernels_f64 : kernels_f32)[variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
+#undef RT_K
+    hipLaunchKernelGGL(kernels[exact ? 1 : 0][(s->lane && s->tree) ? 1 : 0][variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -212,6 +223,10 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
             stats_out->shadow_rays = c[3], stats_out->shaded_hits = c[4], stats_out->light_cells = c[5];
             stats_out->pattern_lookups = c[6], stats_out->container_passes = c[7], stats_out->shadow_rays_cast = c[8];
             stats_out->exact_nodes = c[9];
+#ifdef RT_PHASE_CLOCK
+            std::fprintf(stderr, "phase ticks (summed over waves): trace %llu prepare+containers %llu f64 %llu shade %llu children %llu | loop iterations %llu\n",
+                         c[10], c[11], c[12], c[13], c[14], c[15]);
+#endif
         }
     }
     (void)hipFree(d_out);
@@ -256,6 +271,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
     if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
     if (rc == RT_OK) rc = upload(ps.bound, &s->k.bound, s->owned);
+    if (rc == RT_OK) rc = upload(ps.lnodes, &s->k.lnodes, s->owned);
     if (rc == RT_OK) rc = upload(ps.gates, &s->k.gates, s->owned);
     if (rc == RT_OK) rc = upload(ps.extras, &s->k.extras, s->owned);
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
@@ -271,6 +287,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     s->k.any_spawn = ps.any_spawn ? 1u : 0u;
     s->exotic = ps.exotic;
     s->tree = ps.has_bvh || ps.has_gates;
+    // Lane-mode walks (rt_kernel.h LANE) pay where the rays of a tile have little in common or the hierarchy is deep:
+    // measured (profiles/r02_lane_mode.txt) 1 M triangles 10.1 -> 1.8 ms, 100 k 5.2 -> 2.9 ms, C4 (1152 records, glass)
+    // 11.3 -> 9.9 ms, but obj_mesh (1170 records, opaque) 0.40 -> 0.59 ms and 10 k triangles 1.6 -> 1.7 ms.
+    s->lane = ps.has_bvh && (ps.n_items > RT_LANE_BIG_ITEMS || (ps.n_items > RT_LANE_MIN_ITEMS && ps.any_glass));
+    if (const char* force = std::getenv("RT_AMD_LANE")) s->lane = ps.has_bvh && force[0] == '1';  // timing experiments
     s->area = ps.has_area;
     s->k.n_lights = ps.n_lights;
     if (rc == RT_OK) {
@@ -301,7 +322,7 @@ void rt_scene_destroy(rt_scene* s) {
 int rt_scene_variant(const rt_scene* s, uint32_t* flags_out) {
     if (!s || !flags_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_variant: null argument");
     *flags_out = (s->area ? RT_VARIANT_AREA : 0u) | (s->tree ? RT_VARIANT_TREE : 0u) | (s->exotic ? RT_VARIANT_EXOTIC : 0u) |
-                 (s->has_f64 ? RT_VARIANT_F64 : 0u);
+                 (s->has_f64 ? RT_VARIANT_F64 : 0u) | (s->lane ? RT_VARIANT_LANE : 0u);
     return RT_OK;
 }
 

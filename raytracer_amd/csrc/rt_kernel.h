@@ -90,6 +90,7 @@ struct KScene {
     const uint32_t* order;  // per record: world.objects position of the primitive (tie order)
     const uint32_t* gate;   // per record: innermost enclosing Group of the caller's tree, or kNoGate
     const DBound* bound;    // per record: world-space bounding ball (shaft tests)
+    const LNode* lnodes;    // per record: box + skip link in 32 bytes (lane-mode walks)
     const DGate* gates;
     const DExtra* extras;
     const DMaterial* mats;
@@ -118,7 +119,19 @@ struct KParams {
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
-constexpr int kCounters = 10;  // primary, reflect, refract, shadow, shaded, cells, pattern, container, shadow rays CAST, nodes refined in f64
+#ifdef RT_PHASE_CLOCK  // experiment: + iterations of the path loop and s_memtime ticks per phase, summed over waves
+constexpr int kCounters = 16;
+#define RT_TICK(k)                                             \
+    if (STATS) {                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ph[k] += now_ - t_last;                                \
+        t_last = now_;                                         \
+    }
+#else
+#define RT_TICK(k)
+constexpr int kCounters = 10;
+#endif
+constexpr int kCountersBase = 10;  // primary, reflect, refract, shadow, shaded, cells, pattern, container, shadow rays CAST, nodes refined in f64
 
 // the builtin keeps the predicate as a lane mask (s_and with exec); __ballot() goes through a VGPR
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -195,12 +208,69 @@ __device__ __forceinline__ void traverse_masked(const KScene& sc, uint32_t self_
             one(i);
         }
 }
-template <bool TREE, class Enter, class Visit>
-__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
+// Lane mode: every lane walks the hierarchy ON ITS OWN (per-lane loads of the 32-byte LNode records, divergent
+// control), in the order laid out for the sign pattern of ITS ray's direction (rt_math.h LNode: near child
+// first).  The union walk below pays for every record ANY lane's ray can meet — a few dozen for the coherent
+// rays of a tile (camera rays, shadow rays towards one light), nearly the whole stream for the rays of deep
+// glass paths, which leave a tile in 64 directions.  Each round a lane steps through up to RT_LANE_WALK boxes
+// until it stands on a primitive whose own box its ray meets; then the lanes that found one fetch that
+// primitive's 64-byte record and run the visitor together, so the (long) intersection code is not interleaved
+// with box tests.  `stream` = the lane's LNode stream, `i` = where it starts in it.
+#ifndef RT_LANE_MIN_ITEMS
+#define RT_LANE_MIN_ITEMS 96     // streams up to this long are always walked by the wave as one (rt_amd.hip picks the variant)
+#define RT_LANE_BIG_ITEMS 32768  // longer ones always by the lanes; in between: by the lanes if a material is transparent
+#endif
+#ifndef RT_LANE_WALK
+#define RT_LANE_WALK 8
+#endif
+template <class Enter, class Visit>
+__device__ __forceinline__ void traverse_lane(const KScene& sc, const LNode* stream, uint32_t self_prim, bool live, uint32_t i, Enter&& enter_node,
+                                              Visit&& visit) {
+    const uint32_t n = sc.n_items;
+    bool go = live && i < n;
+    while (wave_any(go)) {
+        uint32_t cand = kNoPrim;
+#pragma unroll 1
+        for (int k = 0; k < RT_LANE_WALK; ++k) {
+            if (go && cand == kNoPrim) {
+                const LNode nd = stream[i];
+                const bool in = enter_node(i, nd);
+                const bool is_node = (nd.ref >> kLRefShift) == REC_NODE;
+                cand = (in && !is_node) ? (nd.ref & kLRefMask) : kNoPrim;
+                i = (is_node && !in) ? nd.next : i + 1u;
+                go = i < n;
+            }
+            if (!wave_any(go && cand == kNoPrim)) break;
+        }
+        const bool pend = cand != kNoPrim;
+        if (wave_any(pend)) {
+            bool keep = true;
+            const bool on_self = pend && cand == self_prim;
+            if (wave_any(on_self)) {
+                if (on_self) keep = visit(cand, sc.recs[cand], std::true_type{});
+            }
+            if (pend && !on_self) keep = visit(cand, sc.recs[cand], std::false_type{});
+            go = go && keep;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t octant_of(V3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
+// LANE (a kernel variant, chosen per scene: a hierarchy of more than RT_LANE_MIN_ITEMS records): every walk is a
+// lane-mode walk from the root — in the order of the ray's own direction `dir` when OWN_ORDER (closest-hit and
+// any-hit queries), in the canonical order otherwise (walks whose enter test does not follow a ray: container pass,
+// shaft tests).  Without LANE: the union walk, records through scalar loads.  (A wave that switches from one to the
+// other at run time measured slower than either: both loops with their inlined visitors in one kernel cost the
+// union walk 20 % through register pressure, profiles/r02_lane_mode.txt.)
+template <bool TREE, bool LANE, bool OWN_ORDER, class Enter, class Visit>
+__device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, V3 dir, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
     if (!TREE) {
         traverse_masked<false>(sc, self_prim, live, ~0ull, visit);
+        return;
+    }
+    if (LANE) {
+        traverse_lane(sc, OWN_ORDER ? sc.lnodes + octant_of(dir) * n : sc.lnodes, self_prim, live, 0u, enter_node, visit);
         return;
     }
     uint32_t i = 0;
@@ -235,32 +305,8 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
     }
 }
 
-#if RT_EXP & 256
-// experiment: every lane walks the stream on its own (per-lane record loads, divergent control)
-template <class Enter, class Visit>
-__device__ __forceinline__ void traverse_lane(const KScene& sc, uint32_t self_prim, bool live, Enter&& enter_node, Visit&& visit) {
-    const uint32_t n = sc.n_items;
-    uint32_t i = 0;
-    bool go = live && n != 0u;
-    while (wave_any(go)) {
-        if (go) {
-            const DPrim rec = sc.recs[i];
-            uint32_t to = i + 1u;
-            if (rec.type == REC_NODE) {
-                if (!enter_node(i, rec)) to = rec.material;
-            } else {
-                const bool keep = (i == self_prim) ? visit(i, rec, std::true_type{}) : visit(i, rec, std::false_type{});
-                if (!keep) to = n;
-            }
-            i = to;
-            go = i < n;
-        }
-    }
-}
-#endif
-
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
-template <bool EXOTIC, bool TREE>
+template <bool EXOTIC, bool TREE, bool LANE>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask) {
     bool occ = false;
     auto visit = [&](uint32_t prim, const DPrim& p, auto self) {
@@ -282,7 +328,7 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
     } else {
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if (sc.has_bvh) inv_d = inv_dir(ray.d);
-        traverse<TREE>(sc, ray.self, live, [&](uint32_t, const DPrim& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); }, visit);
+        traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); }, visit);
     }
     return occ;
 }
@@ -342,8 +388,10 @@ constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT) {
 struct Ray64 {
     D3 o, d;
 };
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT>
+// LANE = every lane walks the hierarchy on its own (traverse above); needs TREE.
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false>
 __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT)) void render_kernel(const KParams P) {
+    static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
 #ifdef RT_ORDER
     constexpr uint32_t kOrder = RT_ORDER;  // experiments
 #else
@@ -405,7 +453,14 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
                        c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0, c_refined = 0;
 
+#ifdef RT_PHASE_CLOCK
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     while (wave_any(active)) {
+#ifdef RT_PHASE_CLOCK
+        ph[5]++;
+#endif
         // ---------------------------------------------------------------- trace (world.rs:24-41)
         uint32_t hit_prim = kNoPrim;
         float hit_t = INFINITY, hit_u = 0.0f, hit_v = 0.0f;
@@ -419,7 +474,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         double t64 = 0.0, u64 = 0.0, v64 = 0.0;
         // (The search and the f64 selection are two calls each, the second one rare.)
         auto do_trace = [&](bool live) {
-            auto trace_enter = [&](uint32_t, const DPrim& nd) {
+            auto trace_enter = [&](uint32_t, const auto& nd) {
                 return bvh_node_hit(nd, cur.o, inv_d, 0.0f, hit_t + (EXACT ? amb_window(hit_t) : tie_window(hit_t)));
             };
             auto trace_visit = [&](uint32_t prim, const DPrim& p, auto self) {
@@ -452,11 +507,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     else intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, emit);
                     return true;
                 };
-#if RT_EXP & 256
-            if (TREE && wave_any(live && node != 0u)) traverse_lane(sc, cur.self, live, trace_enter, trace_visit);
-            else
-#endif
-                traverse<TREE>(sc, cur.self, live, trace_enter, trace_visit);
+            traverse<TREE, LANE, true>(sc, cur.self, live, cur.d, trace_enter, trace_visit);
         };
         // Selection in f64 among what FP32 could not order, and for every node that spawns children.  Returns
         // whether f64 found none of the candidates in front of the ray (then they are left out of a second search).
@@ -502,6 +553,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 do_select(retry, false);
             }
         }
+        RT_TICK(0)
         const bool has_hit = active && hit_prim != kNoPrim;
         const uint32_t depth = P.max_depth - level_of(node);  // remaining recursion depth of this node
 
@@ -538,9 +590,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
-            traverse<TREE>(
-                sc, cur.self, need_n,
-                [&](uint32_t, const DPrim& nd) {
+            traverse<TREE, LANE, false>(
+                sc, cur.self, need_n, cur.d,
+                [&](uint32_t, const auto& nd) {
                     // crossings behind the origin count too (sorted list), those beyond the hit never
                     if (EXOTIC) return bvh_node_hit(nd, cur.o, inv_d, -INFINITY, hit_t + tie_window(hit_t));
                     return node_holds_point(nd, hp, hm);  // rt_math.h: spheres and cubes only
@@ -560,6 +612,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 if (STATS) c_container++;
             }
         }
+        RT_TICK(1)
         // ---------------------------------------------------------------- the f64 hit (rt_exact.h), refined nodes
         // The reference's own hit point, normal, inside flag, pattern cell and child rays; the children go
         // straight to private memory (r64[1] reflection, r64[2] refraction).
@@ -604,6 +657,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             if (STATS) c_refined++;
           }
         }
+        RT_TICK(2)
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
         auto ld3 = [&](int k) { return v3(park[k * kBlockThreads], park[(k + 1) * kBlockThreads], park[(k + 2) * kBlockThreads]); };
@@ -659,7 +713,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
-                const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull);
+                const bool occ = occluded<EXOTIC, TREE, LANE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && cast && matters) c_cast++;
@@ -708,9 +762,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         far_front = pb.far_front, no_spec = pb.no_spec || park[13 * kBlockThreads] == 0.0f;  // no specular term at all
                     }
                     blockers = 0;
-                    traverse<TREE>(
-                        sc, h_prim(), walks,
-                        [&](uint32_t i, const DPrim&) {
+                    traverse<TREE, LANE, false>(
+                        sc, h_prim(), walks, sh.D,
+                        [&](uint32_t i, const auto&) {  // (lane mode asks for primitives too: the same ball test as the visitor's)
                             const DBound b = sc.bound[i];
                             return shaft_meets_ball(sh, v3(b.c[0], b.c[1], b.c[2]), b.r);
                         },
@@ -967,7 +1021,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        const bool occ = occluded<EXOTIC, TREE>(sc, sr, dist, cast, by_mask, pass_mask);
+                        const bool occ = occluded<EXOTIC, TREE, LANE>(sc, sr, dist, cast, by_mask, pass_mask);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
@@ -993,6 +1047,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         const V3 eye = ld3(20);
         if (has_hit) acc = acc + w * v3(park[14 * kBlockThreads], park[15 * kBlockThreads], park[16 * kBlockThreads]);
 
+        RT_TICK(3)
         // ---------------------------------------------------------------- children (world.rs:59-69,94-133)
         float m_reflectivity = 0.0f, m_transparency = 0.0f;
         if (has_hit) {
@@ -1059,6 +1114,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 active = false;
             }
         }
+        RT_TICK(4)
     }
 
     {
@@ -1074,6 +1130,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     }
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
+#ifdef RT_PHASE_CLOCK
+        for (int k = 0; k < 6; ++k) v[kCountersBase + k] = lane == 0 ? ph[k] : 0ull;
+#endif
         unsigned long long cast_rays = 0;  // primary + reflection + refraction + shadow rays really traced
         for (int k = 0; k < kCounters; ++k) {
             unsigned long long s = v[k];

@@ -59,6 +59,21 @@ struct DPrim {  // 64 B — one s_load_dwordx16 when the index is wave-uniform
     float ior;          // copy of the material's index_of_refraction (container pass)
     uint32_t extra;     // index into DExtra (cylinder, triangles)
 };
+// The walk order of the lanes that traverse ON THEIR OWN (rt_kernel.h, lane mode): the same hierarchy laid out
+// EIGHT times, once per sign pattern of a ray's direction, each time in depth-first pre-order with the child
+// that such a ray reaches first in front (a node split along x puts its low-x child first for d.x >= 0, its
+// high-x child first for d.x < 0).  A closest-hit walk in its ray's own order meets the near things first and
+// the box tests cull most of what lies behind them.  32 bytes a record: a node's box and skip link, or a
+// primitive's own world-space box (the same widening as the node boxes; +-inf for planes and unbounded cylinders)
+// and the position of its 64-byte record in the canonical stream — a lane only fetches the record of a
+// primitive whose box its ray meets.  Stream k starts at lnodes[k * n_items]; stream 0 is the canonical order.
+struct alignas(32) LNode {
+    float inv[6];   // box min = inv[0..2], max = inv[3..5] (the field names of DPrim: the box tests take either)
+    uint32_t next;  // node: the position after its subtree IN THIS STREAM.  primitive: its position + 1
+    uint32_t ref;   // primitive: type << kLRefShift | record index in the canonical stream.  node: REC_NODE << kLRefShift
+};
+constexpr uint32_t kLRefShift = 29u;
+constexpr uint32_t kLRefMask = (1u << kLRefShift) - 1u;
 struct DExtra {  // 128 B: cylinder {min,max,closed}; triangle {v0,e0,e1,normal,n0,n1,n2}
     float f[32];
 };
@@ -486,7 +501,8 @@ RT_HD bool gates_pass(const DGate* gates, uint32_t g, V3 o, V3 d) {
 // skip link in `material`.  Plain slab test on the parameter interval [t_lo, t_hi]; a NaN from
 // 0 * inf (origin on a slab plane, direction parallel to it) drops out of min/max, which keeps the
 // test conservative.  inv_d = 1 / direction, per component.
-RT_HD bool bvh_node_hit(const DPrim& n, V3 o, V3 inv_d, float t_lo, float t_hi) {
+template <class Rec>
+RT_HD bool bvh_node_hit(const Rec& n, V3 o, V3 inv_d, float t_lo, float t_hi) {
     float x0 = (n.inv[0] - o.x) * inv_d.x, x1 = (n.inv[3] - o.x) * inv_d.x;
     float y0 = (n.inv[1] - o.y) * inv_d.y, y1 = (n.inv[4] - o.y) * inv_d.y;
     float z0 = (n.inv[2] - o.z) * inv_d.z, z1 = (n.inv[5] - o.z) * inv_d.z;
@@ -501,7 +517,8 @@ RT_HD V3 inv_dir(V3 d) { return v3(rcp_f(d.x), rcp_f(d.y), rcp_f(d.z)); }
 // within the tie window of its surface — and therefore inside every hierarchy box around it, padded
 // by that window.  (Open cylinders and triangles can be crossed once; scenes holding them keep the
 // ray-interval test.)  m = the padding, in world units.
-RT_HD bool node_holds_point(const DPrim& n, V3 p, float m) {
+template <class Rec>
+RT_HD bool node_holds_point(const Rec& n, V3 p, float m) {
     return (p.x >= n.inv[0] - m) & (p.x <= n.inv[3] + m) & (p.y >= n.inv[1] - m) & (p.y <= n.inv[4] + m) & (p.z >= n.inv[2] - m) &
            (p.z <= n.inv[5] + m);
 }

@@ -32,6 +32,7 @@ struct PackedScene {
     std::vector<uint32_t> order;  // per record: the primitive's position in world.objects order (nodes: 0)
     std::vector<uint32_t> gate;   // per record: innermost enclosing Group (index into gates) or kNoGate
     std::vector<DBound> bound;    // per record: world-space bounding ball (shaft tests)
+    std::vector<LNode> lnodes;    // per record: the compact twin of the stream (lane-mode walks)
     std::vector<DGate> gates;     // the caller's Groups
     std::vector<DExtra> extras;
     std::vector<DMaterial> mats;
@@ -48,6 +49,7 @@ struct PackedScene {
     uint32_t max_cells = 1;              // largest usteps*vsteps over the lights
     bool has_gates = false, has_bvh = false, exotic = false, has_area = false;
     bool any_spawn = false;  // some material is reflective or transparent
+    bool any_glass = false;  // some material is transparent (paths branch: rays of a tile soon have little in common)
 };
 
 constexpr uint32_t kFlatLimit = 8;  // at most this many primitives and no Groups: no hierarchy
@@ -225,59 +227,170 @@ inline DBound node_ball(const DPrim& node) {
     return b;
 }
 
+// The device's own hierarchy over the bounded primitives: a binary tree built top-down with the surface-area
+// heuristic (16 bins per axis over the centroids; expected cost of a split = area(left) * n(left) + area(right) *
+// n(right); the median along the widest axis when the bins cannot separate anything), at most two primitives
+// per leaf.  It is emitted once in canonical order (low side of every split first) into the record stream, and
+// eight times — one per sign pattern of a ray direction — into the compact LNode streams (rt_math.h).
 struct BvhBuild {
+    struct TNode {
+        HostBox box;
+        int left = -1, right = -1;  // subtrees (indices into `tree`), or -1
+        int axis = 0;               // split axis (inner nodes)
+        uint32_t lo = 0, hi = 0;    // leaf: perm[lo, hi) (1 or 2 primitives); a single primitive has no box record
+        uint32_t rec = 0;           // position of the node's record in the canonical stream (boxed nodes)
+    };
     std::vector<HostBox> boxes;  // per bounded primitive (index into `ids`)
     std::vector<uint32_t> ids;   // item index of each bounded primitive
     std::vector<uint32_t> perm;  // working permutation
+    std::vector<TNode> tree;
+    std::vector<uint32_t> prim_rec;  // per bounded primitive k: its position in the canonical stream
     PackedScene* out = nullptr;
     const std::vector<DPrim>* item_rec = nullptr;  // record of each item (primitives only)
     const std::vector<uint32_t>* item_gate = nullptr;
 
+    static double area(const HostBox& b) {
+        const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    int build(uint32_t lo, uint32_t hi, int depth = 0) {  // perm[lo, hi) -> index into `tree`
+        const uint32_t n = hi - lo;
+        TNode node;
+        node.box = HostBox::empty();
+        HostBox cen = HostBox::empty();
+        for (uint32_t k = lo; k < hi; ++k) {
+            const HostBox& b = boxes[perm[k]];
+            node.box.merge(b);
+            double c[3] = {0.5 * (b.mn[0] + b.mx[0]), 0.5 * (b.mn[1] + b.mx[1]), 0.5 * (b.mn[2] + b.mx[2])};
+            cen.add(c);
+        }
+        node.lo = lo, node.hi = hi;
+        if (n <= 2) {
+            tree.push_back(node);
+            return static_cast<int>(tree.size()) - 1;
+        }
+        constexpr int kBins = 16;
+        int best_axis = -1, best_bin = 0;
+        double best_cost = INFINITY;
+        for (int axis = 0; axis < 3; ++axis) {
+            const double c0 = cen.mn[axis], ext = cen.mx[axis] - cen.mn[axis];
+            if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+            HostBox bin_box[kBins];
+            uint32_t bin_n[kBins] = {0};
+            for (auto& b : bin_box) b = HostBox::empty();
+            for (uint32_t k = lo; k < hi; ++k) {
+                const HostBox& b = boxes[perm[k]];
+                int bi = static_cast<int>((0.5 * (b.mn[axis] + b.mx[axis]) - c0) / ext * kBins);
+                bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+                bin_box[bi].merge(b), bin_n[bi]++;
+            }
+            double right_area[kBins];
+            uint32_t right_n[kBins];
+            HostBox acc = HostBox::empty();
+            uint32_t cnt = 0;
+            for (int i = kBins - 1; i > 0; --i) {
+                if (bin_n[i]) acc.merge(bin_box[i]);
+                cnt += bin_n[i];
+                right_area[i] = area(acc), right_n[i] = cnt;
+            }
+            acc = HostBox::empty(), cnt = 0;
+            for (int i = 0; i + 1 < kBins; ++i) {  // split between bin i and bin i + 1
+                if (bin_n[i]) acc.merge(bin_box[i]);
+                cnt += bin_n[i];
+                if (cnt == 0 || right_n[i + 1] == 0) continue;
+                const double cost = area(acc) * cnt + right_area[i + 1] * right_n[i + 1];
+                if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = i;
+            }
+        }
+        uint32_t mid = lo + n / 2;
+        if (best_axis >= 0 && depth < 40) {  // (deeper than that the splits are lopsided: halve instead)
+            const int axis = best_axis;
+            const double c0 = cen.mn[axis], ext = cen.mx[axis] - cen.mn[axis];
+            auto bin_of = [&](uint32_t a) {
+                int bi = static_cast<int>((0.5 * (boxes[a].mn[axis] + boxes[a].mx[axis]) - c0) / ext * kBins);
+                return bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+            };
+            auto it = std::stable_partition(perm.begin() + lo, perm.begin() + hi, [&](uint32_t a) { return bin_of(a) <= best_bin; });
+            mid = static_cast<uint32_t>(it - perm.begin());
+            node.axis = axis;
+        }
+        if (best_axis < 0 || depth >= 40 || mid == lo || mid == hi) {  // nothing to separate by: the median along the widest axis
+            int axis = 0;
+            double ext = -1.0;
+            for (int k = 0; k < 3; ++k)
+                if (cen.mx[k] - cen.mn[k] > ext) ext = cen.mx[k] - cen.mn[k], axis = k;
+            mid = lo + n / 2;
+            std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, [&](uint32_t a, uint32_t b) {
+                const double ca = boxes[a].mn[axis] + boxes[a].mx[axis], cb = boxes[b].mn[axis] + boxes[b].mx[axis];
+                return ca < cb || (ca == cb && a < b);
+            });
+            node.axis = axis;
+        }
+        const int l = build(lo, mid, depth + 1);
+        const int r = build(mid, hi, depth + 1);
+        node.left = l, node.right = r;
+        tree.push_back(node);
+        return static_cast<int>(tree.size()) - 1;
+    }
     void emit_prim(uint32_t k) {
         const uint32_t item = ids[k];
+        prim_rec[k] = static_cast<uint32_t>(out->recs.size());
         out->recs.push_back((*item_rec)[item]);
         out->order.push_back(item);
         out->gate.push_back((*item_gate)[item]);
     }
-    void build(uint32_t lo, uint32_t hi) {  // perm[lo, hi)
-        const uint32_t n = hi - lo;
-        if (n == 1) {
-            emit_prim(perm[lo]);
+    // canonical stream: pre-order, low side first
+    void emit(int t) {
+        TNode& nd = tree[t];
+        if (nd.left < 0 && nd.hi - nd.lo == 1) {
+            emit_prim(perm[nd.lo]);
             return;
         }
-        HostBox all = HostBox::empty(), cen = HostBox::empty();
-        for (uint32_t k = lo; k < hi; ++k) {
-            const HostBox& b = boxes[perm[k]];
-            all.merge(b);
-            double c[3] = {0.5 * (b.mn[0] + b.mx[0]), 0.5 * (b.mn[1] + b.mx[1]), 0.5 * (b.mn[2] + b.mx[2])};
-            cen.add(c);
-        }
         const size_t at = out->recs.size();
+        nd.rec = static_cast<uint32_t>(at);
         DPrim node{};
         for (int k = 0; k < 3; ++k) {
-            node.inv[k] = widen(std::nextafter(static_cast<float>(all.mn[k]), -INFINITY), false);
-            node.inv[3 + k] = widen(std::nextafter(static_cast<float>(all.mx[k]), INFINITY), true);
+            node.inv[k] = widen(std::nextafter(static_cast<float>(nd.box.mn[k]), -INFINITY), false);
+            node.inv[3 + k] = widen(std::nextafter(static_cast<float>(nd.box.mx[k]), INFINITY), true);
         }
         node.type = REC_NODE;
         out->recs.push_back(node);
         out->order.push_back(0);
         out->gate.push_back(kNoGate);
-        if (n <= 2) {
-            for (uint32_t k = lo; k < hi; ++k) emit_prim(perm[k]);
+        if (nd.left < 0) {
+            for (uint32_t k = nd.lo; k < nd.hi; ++k) emit_prim(perm[k]);
         } else {
-            int axis = 0;
-            double ext = -1.0;
-            for (int k = 0; k < 3; ++k)
-                if (cen.mx[k] - cen.mn[k] > ext) ext = cen.mx[k] - cen.mn[k], axis = k;
-            const uint32_t mid = lo + n / 2;
-            std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, [&](uint32_t a, uint32_t b) {
-                const double ca = boxes[a].mn[axis] + boxes[a].mx[axis], cb = boxes[b].mn[axis] + boxes[b].mx[axis];
-                return ca < cb || (ca == cb && a < b);
-            });
-            build(lo, mid);
-            build(mid, hi);
+            emit(nd.left);
+            emit(nd.right);
         }
         out->recs[at].material = static_cast<uint32_t>(out->recs.size());  // skip link
+    }
+    // the compact stream of one direction octant (bit k of `oct` set: the ray's direction is negative along axis k)
+    void emit_lane(int t, uint32_t oct, std::vector<LNode>& dst, const std::vector<LNode>& prim_node) const {
+        const TNode& nd = tree[t];
+        if (nd.left < 0 && nd.hi - nd.lo == 1) {
+            LNode ln = prim_node[prim_rec[perm[nd.lo]]];
+            ln.next = static_cast<uint32_t>(dst.size()) + 1u;
+            dst.push_back(ln);
+            return;
+        }
+        const size_t at = dst.size();
+        LNode ln{};
+        for (int k = 0; k < 6; ++k) ln.inv[k] = out->recs[nd.rec].inv[k];
+        ln.ref = REC_NODE << kLRefShift;
+        dst.push_back(ln);
+        if (nd.left < 0) {
+            for (uint32_t k = nd.lo; k < nd.hi; ++k) {
+                LNode pl = prim_node[prim_rec[perm[k]]];
+                pl.next = static_cast<uint32_t>(dst.size()) + 1u;
+                dst.push_back(pl);
+            }
+        } else {
+            const bool flip = ((oct >> nd.axis) & 1u) != 0;
+            emit_lane(flip ? nd.right : nd.left, oct, dst, prim_node);
+            emit_lane(flip ? nd.left : nd.right, oct, dst, prim_node);
+        }
+        dst[at].next = static_cast<uint32_t>(dst.size());
     }
 };
 
@@ -332,6 +445,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         const float* m = d->mat_param + 8 * i;
         out.mats.push_back(DMaterial{m[0], m[1], m[2], m[3], m[4], m[5], m[6], d->mat_pattern[i]});
         out.any_spawn |= !(std::fabs(m[5]) <= kEps) || !(std::fabs(m[6]) <= kEps);
+        out.any_glass |= !(std::fabs(m[6]) <= kEps);
         if (out.has_f64) out.xior.push_back(d->mat_ior64[i]);
     }
     std::vector<DPrim> prims;  // by primitive index
@@ -415,10 +529,12 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         out.order.push_back(item);
         out.gate.push_back(item_gate[item]);
     };
+    BvhBuild b;
+    int root = -1;
+    uint32_t n_top = 0;
     if (prim_items.size() <= kFlatLimit && !out.has_gates) {
         for (uint32_t item : prim_items) emit_flat(item);
     } else {
-        BvhBuild b;
         b.out = &out, b.item_rec = &item_rec, b.item_gate = &item_gate;
         for (uint32_t item : prim_items) {
             const uint32_t ref = d->item_ref[item];
@@ -431,8 +547,11 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
             for (uint32_t item : b.ids) emit_flat(item);
         } else {
             b.perm.resize(b.ids.size());
+            b.prim_rec.assign(b.ids.size(), 0u);
             for (uint32_t k = 0; k < b.perm.size(); ++k) b.perm[k] = k;
-            b.build(0, static_cast<uint32_t>(b.perm.size()));
+            root = b.build(0, static_cast<uint32_t>(b.perm.size()));
+            n_top = static_cast<uint32_t>(out.recs.size());  // the unbounded primitives in front of the tree
+            b.emit(root);
             out.has_bvh = true;
         }
     }
@@ -440,6 +559,40 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     if (out.recs.empty()) out.recs.push_back(DPrim{}), out.order.push_back(0), out.gate.push_back(kNoGate);
     for (const DPrim& r : out.recs)
         out.bound.push_back(r.type == REC_NODE ? node_ball(r) : prim_world_ball(r.type, r.inv, out.extras[r.extra].f));
+    if (out.recs.size() >= (1u << kLRefShift)) {
+        err = "too many records for the compact streams";
+        return RT_ERR_CAPACITY;
+    }
+    {  // the compact twin of every record, canonical order (stream 0 of the lane-mode walks)
+        std::vector<LNode> canon;
+        for (size_t i = 0; i < out.recs.size(); ++i) {
+            const DPrim& r = out.recs[i];
+            LNode ln{};
+            if (r.type == REC_NODE) {
+                for (int k = 0; k < 6; ++k) ln.inv[k] = r.inv[k];
+                ln.next = r.material;
+                ln.ref = REC_NODE << kLRefShift;
+            } else {
+                const HostBox box = prim_world_box(r.type, r.inv, out.extras[r.extra].f);
+                for (int k = 0; k < 3; ++k) {
+                    ln.inv[k] = box.bounded ? widen(std::nextafter(static_cast<float>(box.mn[k]), -INFINITY), false) : -INFINITY;
+                    ln.inv[3 + k] = box.bounded ? widen(std::nextafter(static_cast<float>(box.mx[k]), INFINITY), true) : INFINITY;
+                }
+                ln.next = static_cast<uint32_t>(i) + 1u;
+                ln.ref = (r.type << kLRefShift) | static_cast<uint32_t>(i);
+            }
+            canon.push_back(ln);
+        }
+        out.lnodes = canon;
+        if (out.has_bvh) {  // + the seven other direction orders of the same tree
+            for (uint32_t oct = 1; oct < 8; ++oct) {
+                std::vector<LNode> dst(canon.begin(), canon.begin() + n_top);
+                b.emit_lane(root, oct, dst, canon);
+                if (dst.size() != canon.size()) return bad("internal: direction-ordered stream of the wrong length");
+                out.lnodes.insert(out.lnodes.end(), dst.begin(), dst.end());
+            }
+        }
+    }
     if (out.has_f64) {  // record i of the stream is the primitive of item order[i]
         out.xprims.resize(out.recs.size());
         for (size_t i = 0; i < out.n_items; ++i) {

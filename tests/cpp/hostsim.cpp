@@ -597,3 +597,90 @@ extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_de
     out[6] = g_audit_front, out[7] = g_audit_dull, out[8] = g_audit_phong_violations, out[9] = g_audit_behind;
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The direction-ordered compact streams of rt_pack.h (lane-mode walks of rt_kernel.h): structure of all eight, and
+// a closest-hit query through the ray's own stream against the same query through the canonical record stream, on
+// random rays.  out[0] = structural errors, out[1] = rays whose two answers differ, out[2] = records looked at in
+// canonical order, out[3] = records looked at in the ray's own order (both summed over the rays), out[4] = n_items,
+// out[5] = rays that hit something.
+extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int n_rays, uint32_t seed, const float* box6, uint64_t* out,
+                                          char* err_out, int err_cap) {
+    PackedScene ps;
+    std::string err;
+    const int rc = pack_scene(desc, ps, err);
+    if (rc != RT_OK) {
+        if (err_out && err_cap > 0) std::snprintf(err_out, static_cast<size_t>(err_cap), "%s", err.c_str());
+        return rc;
+    }
+    const uint32_t n = ps.n_items;
+    const uint32_t streams = ps.has_bvh ? 8u : 1u;
+    uint64_t bad = 0;
+    if (ps.lnodes.size() != static_cast<size_t>(streams) * std::max<size_t>(ps.recs.size(), 1)) bad++;
+    for (uint32_t k = 0; k < streams && !bad; ++k) {
+        const LNode* st = ps.lnodes.data() + static_cast<size_t>(k) * n;
+        std::vector<uint8_t> seen(n, 0);
+        std::vector<uint32_t> ends;  // open subtrees
+        for (uint32_t i = 0; i < n; ++i) {
+            while (!ends.empty() && ends.back() == i) ends.pop_back();
+            const uint32_t type = st[i].ref >> kLRefShift, ref = st[i].ref & kLRefMask;
+            if (st[i].next <= i || st[i].next > n) bad++;
+            if (!ends.empty() && st[i].next > ends.back()) bad++;
+            if (type == REC_NODE) {
+                if (st[i].next > i + 1) ends.push_back(st[i].next);
+            } else {
+                if (st[i].next != i + 1 || ref >= n || seen[ref] || ps.recs[ref].type != type) bad++;
+                else seen[ref] = 1;
+            }
+        }
+        for (uint32_t i = 0; i < n; ++i)
+            if (ps.recs[i].type != REC_NODE && !seen[i]) bad++;
+    }
+    out[0] = bad, out[1] = out[2] = out[3] = out[5] = 0, out[4] = n;
+    if (bad) return RT_OK;
+    uint32_t state = seed * 2654435761u + 12345u;
+    auto rnd = [&] {
+        state = state * 1664525u + 1013904223u;
+        return static_cast<float>(state >> 8) * (1.0f / 16777216.0f);
+    };
+    auto query = [&](const LNode* st, const Ray& ray, uint64_t& looked, uint32_t& prim_out, float& t_out) {
+        const V3 inv_d = inv_dir(ray.d);
+        prim_out = kNoPrim, t_out = INFINITY;
+        for (uint32_t i = 0; i < n;) {
+            const LNode& nd = st[i];
+            ++looked;
+            const bool in = bvh_node_hit(nd, ray.o, inv_d, 0.0f, t_out + tie_window(t_out));
+            if ((nd.ref >> kLRefShift) == REC_NODE) {
+                i = in ? i + 1 : nd.next;
+                continue;
+            }
+            ++i;
+            if (!in) continue;
+            const uint32_t prim = nd.ref & kLRefMask;
+            intersect_prim(ps.recs[prim], ps.extras.data(), ray, false, [&](int, float t, float, float) {
+                bool better = closer_hit(t, t_out);
+                if (!better && prim_out != kNoPrim && ties_hit(t, t_out)) better = ps.order[prim] < ps.order[prim_out];
+                if (better) prim_out = prim, t_out = t;
+            });
+        }
+    };
+    for (int r = 0; r < n_rays; ++r) {
+        Ray ray;
+        ray.o = v3(box6[0] + rnd() * (box6[3] - box6[0]), box6[1] + rnd() * (box6[4] - box6[1]), box6[2] + rnd() * (box6[5] - box6[2]));
+        V3 d = v3(rnd() * 2.0f - 1.0f, rnd() * 2.0f - 1.0f, rnd() * 2.0f - 1.0f);
+        const float len = std::sqrt(dot(d, d));
+        if (!(len > 1e-3f)) continue;
+        ray.d = d * (1.0f / len);
+        ray.self = kNoPrim, ray.q = v3(0, 0, 0), ray.dq = v3(0, 0, 0);
+        uint32_t pa, pb;
+        float ta, tb;
+        query(ps.lnodes.data(), ray, out[2], pa, ta);
+        const uint32_t oct = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
+        query(ps.lnodes.data() + static_cast<size_t>(streams == 8 ? oct : 0) * n, ray, out[3], pb, tb);
+        if (pa != kNoPrim) out[5]++;
+        // the two orders may settle a tie inside the tie window differently; anything else is an error
+        if (pa != pb && !(pa != kNoPrim && pb != kNoPrim && ties_hit(ta, tb))) out[1]++;
+        else if (pa == pb && pa != kNoPrim && ta != tb) out[1]++;
+    }
+    return RT_OK;
+}
