@@ -202,7 +202,15 @@ int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint
  * red/green/blue per pixel — the Canvas contents in canvas.rs:8-12 order.
  *   rt_render_device: rgb_out is DEVICE memory on the scene's GPU; the work is enqueued on
  *                     `stream` (a hipStream_t passed as void*, NULL = the default stream) and the
- *                     call returns without waiting.  Allocates nothing.
+ *                     call returns without waiting.  Allocates nothing, with one exception: a scene
+ *                     with transparent materials keeps a tile-cost table of 20 bytes per 8x8 tile
+ *                     (every wave leaves the time its tile took; the next frame with the same tiling
+ *                     starts its expensive tiles first — same image, shorter tail).  The first call
+ *                     with a frame of 8192 tiles or more that is larger than any before waits for the
+ *                     stream, allocates that table and keeps it until rt_scene_destroy
+ *                     (RT_AMD_NO_TILE_ORDER=1 in the environment: never).  Calls on one scene must be
+ *                     ordered on the device as well (one stream, or events between streams).
+ *                     rt_render_stats_noalloc never allocates and does not reorder.
  *   rt_render:        rgb_out is HOST memory; the call allocates a device image, renders, copies
  *                     back and waits.  stats_out may be NULL. */
 int rt_render_device(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,

@@ -4,6 +4,7 @@
 // side of the ABI: validation, upload, launch, copies, error strings.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -132,12 +133,23 @@ struct rt_scene {
     std::vector<void*> owned;
     unsigned long long* counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // tile order (rt_kernel.h "Tile order"): scenes with transparent materials keep 20 bytes per tile of the largest
+    // frame rendered so far — the cost of each tile in the last frame, and two sets of class words + order
+    bool ordered = false;
+    uint32_t* order_buf = nullptr;
+    uint32_t order_cap = 0;                       // tiles the buffer holds
+    uint32_t cost_tiles = 0, cost_tiles_x = 0;    // tiling of the frame whose costs the table holds (0: none yet)
+    uint32_t order_flip = 0;
 };
 
 namespace {
 
+// Frames of fewer tiles than the chip holds waves at once (256 CUs x 4 SIMDs x 5) start all their tiles together anyway.
+constexpr uint32_t kOrderMinTiles = 8192;
+
 int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt, const RenderPlan& rp, float* d_out,
-                  hipStream_t stream, bool stats, unsigned long long* counters = nullptr, uint32_t* tile_rays = nullptr) {
+                  hipStream_t stream, bool stats, unsigned long long* counters = nullptr, uint32_t* tile_rays = nullptr,
+                  bool allow_order = true) {
     KParams P{};
     P.sc = s->k;
     P.cam = pack_camera(*cam);
@@ -146,6 +158,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.out = d_out;
     P.counters = counters ? counters : s->counters;
     P.tile_rays = tile_rays;
+    P.tile_order = nullptr;
+    P.tile_cost = nullptr;
     P.max_depth = rp.max_depth;
     P.jitter_mode = opt ? opt->jitter_mode : 0u;
     P.seed = opt ? opt->seed : 0u;
@@ -157,6 +171,31 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     P.n_tiles = P.tiles_x * tiles_y;
     if (stats) HIP_TRY(hipMemsetAsync(P.counters, 0, kCounters * sizeof(unsigned long long), stream));
     if (P.n_tiles == 0) return RT_OK;
+    if (s->ordered && allow_order && P.n_tiles >= kOrderMinTiles && !std::getenv("RT_AMD_NO_TILE_ORDER")) {
+        // layout of order_buf: [cost: cap][2 x (counters + class words: 32 + cap)][2 x order: cap]
+        if (P.n_tiles > s->order_cap) {  // first call with a frame this large: (re)allocate, then keep
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (s->order_buf) (void)hipFree(s->order_buf);
+            s->order_buf = nullptr, s->order_cap = 0, s->cost_tiles = 0;
+            const size_t words = 5u * static_cast<size_t>(P.n_tiles) + 2u * kOrderClasses;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->order_buf), words * sizeof(uint32_t)));
+            s->order_cap = P.n_tiles;
+        }
+        const size_t cap = s->order_cap;
+        uint32_t* cost = s->order_buf;
+        if (s->cost_tiles == P.n_tiles && s->cost_tiles_x == P.tiles_x) {  // the last frame had this tiling: its costs order this one
+            s->order_flip ^= 1u;  // (two sets: the kernels of the call before may still be reading theirs)
+            uint32_t* cls = s->order_buf + cap + s->order_flip * (kOrderClasses + cap);
+            uint32_t* order = s->order_buf + cap + 2u * (kOrderClasses + cap) + s->order_flip * cap;
+            HIP_TRY(hipMemsetAsync(cls, 0, kOrderClasses * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(tile_class_kernel, dim3((P.n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, P.n_tiles, cost, cls);
+            hipLaunchKernelGGL(tile_order_kernel, dim3((P.n_tiles + 255u) / 256u), dim3(256), 0, stream, P.n_tiles, cls, order);
+            HIP_TRY(hipGetLastError());
+            P.tile_order = order;
+        }
+        P.tile_cost = cost;
+        s->cost_tiles = P.n_tiles, s->cost_tiles_x = P.tiles_x;
+    }
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
     // 48 instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
@@ -290,6 +329,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     // Lane-mode walks (rt_kernel.h LANE) pay where the rays of a tile have little in common or the hierarchy is deep:
     // measured (profiles/r02_lane_mode.txt) 1 M triangles 10.1 -> 1.8 ms, 100 k 5.2 -> 2.9 ms, C4 (1152 records, glass)
     // 11.3 -> 9.9 ms, but obj_mesh (1170 records, opaque) 0.40 -> 0.59 ms and 10 k triangles 1.6 -> 1.7 ms.
+    s->ordered = ps.any_glass;
     s->lane = ps.has_bvh && (ps.n_items > RT_LANE_BIG_ITEMS || (ps.n_items > RT_LANE_MIN_ITEMS && ps.any_glass));
     if (const char* force = std::getenv("RT_AMD_LANE")) s->lane = ps.has_bvh && force[0] == '1';  // timing experiments
     s->area = ps.has_area;
@@ -314,6 +354,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
+    if (s->order_buf) (void)hipFree(s->order_buf);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -377,7 +418,7 @@ int rt_render_stats_noalloc(rt_scene* scene, const rt_camera_desc* camera, const
     // the counters start at zero (launch_render clears them on the stream); every tile of the map is
     // written by its wave, so the last call's map needs no clearing
     HIP_TRY(hipEventRecord(scene->ev0, st));
-    rc = launch_render(scene, camera, options, rp, rgb_out_device, st, true, sp->counters, sp->tile_rays);
+    rc = launch_render(scene, camera, options, rp, rgb_out_device, st, true, sp->counters, sp->tile_rays, false);  // (no tile order: it would allocate)
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->ev1, st));
     unsigned long long c[kCounters] = {0};

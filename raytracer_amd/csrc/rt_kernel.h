@@ -112,6 +112,8 @@ struct KParams {
     float* out;
     unsigned long long* counters;  // STATS variant only: kCounters x u64
     uint32_t* tile_rays;           // STATS variant only, may be null: rays cast per 8x8 tile, raster order of this call's rows
+    const uint32_t* tile_order;    // may be null: the tile slot each wave renders (expensive tiles first), else the wave's own index
+    uint32_t* tile_cost;           // may be null: per tile (raster index), the clock ticks its wave ran for
     uint32_t max_depth, jitter_mode, seed;
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
@@ -393,13 +395,16 @@ template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE =
 __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT)) void render_kernel(const KParams P) {
     static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
 #ifdef RT_ORDER
-    constexpr uint32_t kOrder = RT_ORDER;  // experiments
+    constexpr uint32_t kOrder0 = RT_ORDER;  // experiments
 #else
-    constexpr uint32_t kOrder = AREA ? 1u : 0u;
+    constexpr uint32_t kOrder0 = AREA ? 1u : 0u;
 #endif
+    const uint32_t kOrder = P.tile_order ? 0u : kOrder0;  // an explicit tile order names raster slots
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (wave >= P.n_tiles) return;
+    const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave_id >= P.n_tiles) return;
+    const uint32_t wave = P.tile_order ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
+    uint32_t n_rounds = 0;  // rounds of the path loop: what the tile cost its wave (see "Tile order" below)
     const KScene& sc = P.sc;
 
     uint32_t x, yl, gy;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     while (wave_any(active)) {
+        ++n_rounds;
 #ifdef RT_PHASE_CLOCK
         ph[5]++;
 #endif
@@ -1128,6 +1134,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }
+    if (P.tile_cost) {
+        uint32_t tx, tyl, tgy;
+        pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
+        if (lane == 0) P.tile_cost[(tyl >> 3) * P.tiles_x + (tx >> 3)] = n_rounds;
+    }
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
 #ifdef RT_PHASE_CLOCK
@@ -1146,6 +1157,50 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             if (lane == 0) P.tile_rays[(tyl >> 3) * P.tiles_x + (tx >> 3)] = static_cast<uint32_t>(cast_rays);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile order.  Tiles differ in cost by an order of magnitude (a tile of deep glass paths casts 40 rays a pixel,
+// a tile of matte floor 2), one wave renders one tile, and the frame is over when the last wave is: an expensive
+// tile that starts late IS the tail of the kernel.  With the tiles in descending order of cost C4 4K ran 10.5 ->
+// 8.7 ms and cover_image 1.54 -> 1.31 ms (profiles/r02_tile_order.txt); an order guessed from the material a
+// tile's camera rays hit gained a third of that on C4, nothing on cover_image, and lost on other scenes.  So the
+// cost is MEASURED: every wave leaves the number of rounds its path loop took (the deepest pixel of the tile sets
+// it; each round is one trace + one shading pass of the whole wave) in a per-tile table of its scene, one store
+// per wave, and the next frame of that scene with the same tiling deals its tiles out by that table, most
+// expensive first — exact for a camera that stands still (the bench, a turntable's held frame), a good estimate
+// for one that moves a little; the first frame of a scene or of a new frame size runs in raster order.
+// (Not clock ticks: s_memtime at the top of the kernel counts as a possible write to memory, like the asm of
+// profiles/r02_exact_chain_smem_regression.txt, and turned every scalar record load into a vector load —
+// cover_image 1.5 -> 2.4 ms.)
+// Sorting: 32 classes of two rounds each; rank within a class = arrival (counted per workgroup in LDS, one
+// global atomic per class and workgroup — one per tile on the same words serialises in the L2).
+// order_buf: [0..31] counters per class, [32 .. 32+n) per tile: class << 27 | arrival index within its class.
+constexpr uint32_t kOrderClasses = 32;
+__global__ __launch_bounds__(1024) void tile_class_kernel(uint32_t n_tiles, const uint32_t* cost, uint32_t* order_buf) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
+    if (threadIdx.x < kOrderClasses) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t cls = 0, rank = 0;
+    if (tile < n_tiles) {
+        const uint32_t b = cost[tile] >> 1;
+        cls = b > 31u ? 31u : b;
+        rank = atomicAdd(&s_count[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kOrderClasses) s_base[threadIdx.x] = s_count[threadIdx.x] ? atomicAdd(order_buf + threadIdx.x, s_count[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (tile < n_tiles) order_buf[kOrderClasses + tile] = (cls << 27) | (s_base[cls] + rank);
+}
+// order[position] = tile, the highest class first
+__global__ void tile_order_kernel(uint32_t n_tiles, const uint32_t* order_buf, uint32_t* order) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t v = order_buf[kOrderClasses + tile], cls = v >> 27, at = v & 0x07FFFFFFu;
+    uint32_t base = 0;
+    for (uint32_t c = kOrderClasses - 1u; c > cls; --c) base += order_buf[c];
+    order[base + at] = tile;
 }
 
 __global__ void quantize_kernel(const float* __restrict__ rgb, size_t n, uint8_t* __restrict__ out) {

@@ -360,3 +360,27 @@ def test_large_triangle_soup_matches_the_scalar_spec():
     sim = H.hostsim_render(_W, RtOptions())
     dd = np.abs(gpu - sim).max(axis=-1)
     assert np.median(dd) <= 1e-6 and (dd > 1e-5).mean() <= 1e-2, (float(dd.max()), float((dd > 1e-5).mean()))
+
+
+def test_tile_order_feedback_changes_the_schedule_not_the_image():
+    """A scene with glass keeps the rounds each tile took and starts the next frame's expensive tiles first
+    (rt_kernel.h "Tile order"; frames of >= 8192 tiles).  The first frame runs in raster order, the following ones in
+    the fed-back order: all of them must be the same image, bit for bit, also through the strided band partition."""
+    from raytracer_amd import partition
+    ex = ExampleScene("multiple_glass_and_metallic_spheres", 1024, 576)  # 128 x 72 = 9216 tiles
+    sc = Scene(ex.scene_desc, 0)
+    opt = RtOptions()
+    opt.jitter_mode, opt.seed = 1, 3
+    first, _ = sc.render(ex.camera_desc, opt)
+    second, _ = sc.render(ex.camera_desc, opt)
+    third, st = sc.render(ex.camera_desc, opt, stats=True)
+    assert np.array_equal(first, second) and np.array_equal(first, third)
+    assert st.primary_rays == 1024 * 576
+    # another tiling on the same scene (a band partition: half the tiles, below the threshold), then the full frame again
+    o = partition.rank_options(opt, 1, 2)
+    band, _ = sc.render(ex.camera_desc, o)
+    again, _ = sc.render(ex.camera_desc, opt)
+    sc.close()
+    assert np.array_equal(again, first)
+    rows = np.concatenate([np.arange(b * 8, b * 8 + 8) for b in range(1, 72, 2)])  # bands 1, 3, 5, ... of 8 rows
+    assert np.array_equal(band, first[rows])
