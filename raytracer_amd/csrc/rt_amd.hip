@@ -329,7 +329,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     // Lane-mode walks (rt_kernel.h LANE) pay where the rays of a tile have little in common or the hierarchy is deep:
     // measured (profiles/r02_lane_mode.txt) 1 M triangles 10.1 -> 1.8 ms, 100 k 5.2 -> 2.9 ms, C4 (1152 records, glass)
     // 11.3 -> 9.9 ms, but obj_mesh (1170 records, opaque) 0.40 -> 0.59 ms and 10 k triangles 1.6 -> 1.7 ms.
-    s->ordered = ps.any_glass;
+    s->ordered = ps.any_glass || (std::getenv("RT_AMD_ORDER_ALL") && (ps.any_spawn || ps.has_area));
     s->lane = ps.has_bvh && (ps.n_items > RT_LANE_BIG_ITEMS || (ps.n_items > RT_LANE_MIN_ITEMS && ps.any_glass));
     if (const char* force = std::getenv("RT_AMD_LANE")) s->lane = ps.has_bvh && force[0] == '1';  // timing experiments
     s->area = ps.has_area;

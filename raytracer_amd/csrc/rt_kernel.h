@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave_id >= P.n_tiles) return;
     const uint32_t wave = P.tile_order ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
-    uint32_t n_rounds = 0;  // rounds of the path loop: what the tile cost its wave (see "Tile order" below)
+    uint32_t n_rounds = 0, n_visibility = 0;  // rounds of the path loop, points x light chunks that needed shadow rays: the tile's cost ("Tile order" below)
     const KScene& sc = P.sc;
 
     uint32_t x, yl, gy;
@@ -906,6 +906,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     if (STATS && (dark || open || umbra)) c_shadow += cells;
                     need &= ~__ballot(dark || open || umbra);
                 }
+                if (P.tile_cost) n_visibility += static_cast<uint32_t>(__popcll(need)) * chunks;
 
                 if (RT_EXP & 1024) need = 0;
                 // A tile with many such points (it lies in a penumbra): every lane casts its OWN
@@ -1137,7 +1138,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     if (P.tile_cost) {
         uint32_t tx, tyl, tgy;
         pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
-        if (lane == 0) P.tile_cost[(tyl >> 3) * P.tiles_x + (tx >> 3)] = n_rounds;
+        if (lane == 0) P.tile_cost[(tyl >> 3) * P.tiles_x + (tx >> 3)] = 10u * n_rounds + n_visibility;  // (a round ~ ten visibility passes)
     }
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
@@ -1173,7 +1174,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 // (Not clock ticks: s_memtime at the top of the kernel counts as a possible write to memory, like the asm of
 // profiles/r02_exact_chain_smem_regression.txt, and turned every scalar record load into a vector load —
 // cover_image 1.5 -> 2.4 ms.)
-// Sorting: 32 classes of two rounds each; rank within a class = arrival (counted per workgroup in LDS, one
+// (Area lights: + the points x 64-cell chunks that needed real shadow rays, a round counting as ten of those.)
+// Sorting: 32 classes of 1.6 rounds each; rank within a class = arrival (counted per workgroup in LDS, one
 // global atomic per class and workgroup — one per tile on the same words serialises in the L2).
 // order_buf: [0..31] counters per class, [32 .. 32+n) per tile: class << 27 | arrival index within its class.
 constexpr uint32_t kOrderClasses = 32;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(1024) void tile_class_kernel(uint32_t n_tiles, cons
     __syncthreads();
     uint32_t cls = 0, rank = 0;
     if (tile < n_tiles) {
-        const uint32_t b = cost[tile] >> 1;
+        const uint32_t b = cost[tile] >> 4;
         cls = b > 31u ? 31u : b;
         rank = atomicAdd(&s_count[cls], 1u);
     }
