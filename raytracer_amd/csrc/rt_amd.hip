@@ -204,6 +204,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
 // (timing experiments on ONE family, scripts/exp_build.sh: -DRT_EXP_ONLY_TREE compiles the plain hierarchy kernels only)
 #ifdef RT_EXP_ONLY_TREE
 #define RT_K(S, E, T, A, X, L) render_kernel<S, false, true, false, X, L>
+#elif defined(RT_EXP_ONLY_FLAT_AREA)  // (the headline's kernels only)
+#define RT_K(S, E, T, A, X, L) render_kernel<S, false, false, true, X, false>
 #else
 #define RT_K(S, E, T, A, X, L) render_kernel<S, E, T, A, X, (T) && (L)>
 #endif
