@@ -380,7 +380,8 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
 #define RT_MIN_BLOCKS_PLAIN 5
 #endif
 #ifndef RT_MIN_BLOCKS_PLAIN_X
-#define RT_MIN_BLOCKS_PLAIN_X 5  // the same kernels with the f64 chain (EXACT)
+#define RT_MIN_BLOCKS_PLAIN_X 4  // the same kernels with the f64 chain (EXACT): 128 VGPRs, fewer spills beside the f64 ray copies
+// (profiles/r02_occupancy_exact.txt: C4 4K 8.4 -> 7.5 ms, cover_image 1.31 -> 1.20 ms; 3 and 6 are slower)
 #endif
 constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT) {
     return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
