@@ -171,6 +171,7 @@ pub const RT_VARIANT_TREE: u32 = 2;
 pub const RT_VARIANT_EXOTIC: u32 = 4;
 pub const RT_VARIANT_F64: u32 = 8;
 pub const RT_VARIANT_LANE: u32 = 16;
+pub const RT_VARIANT_SPAWN: u32 = 32;
 pub const RT_MAX_DEPTH: u32 = 8;
 pub const RT_MAX_LIGHTS: u32 = 256;
 pub const RT_MAX_LIGHT_CELLS: u32 = 32768;

@@ -185,7 +185,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
 void rt_scene_destroy(rt_scene* scene);
 
 /* Which instantiation of the render kernel the scene runs — render_kernel<counters, EXOTIC, TREE, AREA,
- * F64, LANE> in rocprofv3 output: RT_VARIANT_* bits (profiling and bench reports; no counterpart in the
+ * F64, LANE, SPAWN> in rocprofv3 output: RT_VARIANT_* bits (profiling and bench reports; no counterpart in the
  * reference).  F64 says the scene carries the f64 tables; the kernel with the f64 chain runs when the
  * camera carries its f64 fields too and RT_FLAG_F32_ONLY is not set. */
 #define RT_VARIANT_AREA 1u     /* some light is an area light                      */
@@ -193,6 +193,7 @@ void rt_scene_destroy(rt_scene* scene);
 #define RT_VARIANT_EXOTIC 4u   /* cylinders or triangles                           */
 #define RT_VARIANT_F64 8u      /* rt_scene_desc.*64 given                          */
 #define RT_VARIANT_LANE 16u    /* a long hierarchy: every lane walks it on its own */
+#define RT_VARIANT_SPAWN 32u   /* some material is reflective or transparent       */
 int rt_scene_variant(const rt_scene* scene, uint32_t* flags_out);
 
 /* Number of output rows a call with these options produces (<= camera vsize). */

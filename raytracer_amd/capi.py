@@ -203,7 +203,7 @@ class Scene:
         cam = camera_desc.contents if hasattr(camera_desc, "contents") else camera_desc
         f64 = bool(v.value & 8) and bool(cam.has_f64) and not (options is not None and options.flags & RT_FLAG_F32_ONLY)
         b = lambda x: "true" if x else "false"  # noqa: E731
-        return f"render_kernel<{b(stats)}, {b(v.value & 4)}, {b(v.value & 2)}, {b(v.value & 1)}, {b(f64)}, {b(v.value & 16)}>"
+        return f"render_kernel<{b(stats)}, {b(v.value & 4)}, {b(v.value & 2)}, {b(v.value & 1)}, {b(f64)}, {b(v.value & 16)}, {b(v.value & 32)}>"
 
     def output_rows(self, camera_desc, options: Optional[RtOptions] = None) -> int:
         rows = C.c_uint32()

@@ -128,6 +128,7 @@ struct rt_scene {
     bool tree = false;    // the stream has hierarchy nodes or Group gates
     bool lane = false;    // a hierarchy long enough for lane-mode walks (rt_kernel.h LANE)
     bool area = false;    // some light is an area light
+    bool spawn = true;    // some material is reflective or transparent (else: the kernels without path code)
     bool has_f64 = false; // the caller gave the f64 tables of the exact chain (rt_exact.h)
     KScene k{};
     std::vector<void*> owned;
@@ -198,32 +199,34 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     }
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
-    // 48 instantiations: counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
+    // 80 instantiations (48 + the 32 union-walk kernels once more without path code): counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
     // (x lane-mode walks for the hierarchy variants)
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
 // (timing experiments on ONE family, scripts/exp_build.sh: -DRT_EXP_ONLY_TREE compiles the plain hierarchy kernels only)
 #ifdef RT_EXP_ONLY_TREE
-#define RT_K(S, E, T, A, X, L) render_kernel<S, false, true, false, X, L>
+#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, true, false, X, L, true>
 #elif defined(RT_EXP_ONLY_FLAT_AREA)  // (the headline's kernels only)
-#define RT_K(S, E, T, A, X, L) render_kernel<S, false, false, true, X, false>
+#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, false, true, X, false, P>
 #else
-#define RT_K(S, E, T, A, X, L) render_kernel<S, E, T, A, X, (T) && (L)>
+#define RT_K(S, E, T, A, X, L, P) render_kernel<S, E, T, A, X, (T) && (L), (P) || ((T) && (L))>
 #endif
-#define RT_KERNELS(X, L)                                                                                         \
-    {RT_K(false, false, false, false, X, L), RT_K(false, false, false, true, X, L),                              \
-     RT_K(false, false, true, false, X, L),  RT_K(false, false, true, true, X, L),                               \
-     RT_K(false, true, false, false, X, L),  RT_K(false, true, false, true, X, L),                               \
-     RT_K(false, true, true, false, X, L),   RT_K(false, true, true, true, X, L),                                \
-     RT_K(true, false, false, false, X, L),  RT_K(true, false, false, true, X, L),                               \
-     RT_K(true, false, true, false, X, L),   RT_K(true, false, true, true, X, L),                                \
-     RT_K(true, true, false, false, X, L),   RT_K(true, true, false, true, X, L),                                \
-     RT_K(true, true, true, false, X, L),    RT_K(true, true, true, true, X, L)}
-    // [f64 chain][lane mode][variant]; lane mode only exists for the hierarchy variants (the others repeat the union kernels)
-    void (*const kernels[2][2][16])(const KParams) = {{RT_KERNELS(false, false), RT_KERNELS(false, true)},
-                                                      {RT_KERNELS(true, false), RT_KERNELS(true, true)}};
+#define RT_KERNELS(X, L, P)                                                                                            \
+    {RT_K(false, false, false, false, X, L, P), RT_K(false, false, false, true, X, L, P),                              \
+     RT_K(false, false, true, false, X, L, P),  RT_K(false, false, true, true, X, L, P),                               \
+     RT_K(false, true, false, false, X, L, P),  RT_K(false, true, false, true, X, L, P),                               \
+     RT_K(false, true, true, false, X, L, P),   RT_K(false, true, true, true, X, L, P),                                \
+     RT_K(true, false, false, false, X, L, P),  RT_K(true, false, false, true, X, L, P),                               \
+     RT_K(true, false, true, false, X, L, P),   RT_K(true, false, true, true, X, L, P),                                \
+     RT_K(true, true, false, false, X, L, P),   RT_K(true, true, false, true, X, L, P),                                \
+     RT_K(true, true, true, false, X, L, P),    RT_K(true, true, true, true, X, L, P)}
+    // [f64 chain][lane mode][spawning materials][variant]; lane mode only exists for the hierarchy variants and only
+    // with the path code (the other entries repeat their neighbours)
+    void (*const kernels[2][2][2][16])(const KParams) = {
+        {{RT_KERNELS(false, false, false), RT_KERNELS(false, false, true)}, {RT_KERNELS(false, true, false), RT_KERNELS(false, true, true)}},
+        {{RT_KERNELS(true, false, false), RT_KERNELS(true, false, true)}, {RT_KERNELS(true, true, false), RT_KERNELS(true, true, true)}}};
 #undef RT_KERNELS
 #undef RT_K
-    hipLaunchKernelGGL(kernels[exact ? 1 : 0][(s->lane && s->tree) ? 1 : 0][variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
+    hipLaunchKernelGGL(kernels[exact ? 1 : 0][(s->lane && s->tree) ? 1 : 0][s->spawn ? 1 : 0][variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -331,6 +334,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     // Lane-mode walks (rt_kernel.h LANE) pay where the rays of a tile have little in common or the hierarchy is deep:
     // measured (profiles/r02_lane_mode.txt) 1 M triangles 10.1 -> 1.8 ms, 100 k 5.2 -> 2.9 ms, C4 (1152 records, glass)
     // 11.3 -> 9.9 ms, but obj_mesh (1170 records, opaque) 0.40 -> 0.59 ms and 10 k triangles 1.6 -> 1.7 ms.
+    s->spawn = ps.any_spawn;
     s->ordered = ps.any_glass || (std::getenv("RT_AMD_ORDER_ALL") && (ps.any_spawn || ps.has_area));
     s->lane = ps.has_bvh && (ps.n_items > RT_LANE_BIG_ITEMS || (ps.n_items > RT_LANE_MIN_ITEMS && ps.any_glass));
     if (const char* force = std::getenv("RT_AMD_LANE")) s->lane = ps.has_bvh && force[0] == '1';  // timing experiments
@@ -365,7 +369,7 @@ void rt_scene_destroy(rt_scene* s) {
 int rt_scene_variant(const rt_scene* s, uint32_t* flags_out) {
     if (!s || !flags_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_variant: null argument");
     *flags_out = (s->area ? RT_VARIANT_AREA : 0u) | (s->tree ? RT_VARIANT_TREE : 0u) | (s->exotic ? RT_VARIANT_EXOTIC : 0u) |
-                 (s->has_f64 ? RT_VARIANT_F64 : 0u) | (s->lane ? RT_VARIANT_LANE : 0u);
+                 (s->has_f64 ? RT_VARIANT_F64 : 0u) | (s->lane ? RT_VARIANT_LANE : 0u) | ((s->spawn || (s->lane && s->tree)) ? RT_VARIANT_SPAWN : 0u);
     return RT_OK;
 }
 

@@ -383,8 +383,14 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
 #define RT_MIN_BLOCKS_PLAIN_X 4  // the same kernels with the f64 chain (EXACT): 128 VGPRs, fewer spills beside the f64 ray copies
 // (profiles/r02_occupancy_exact.txt: C4 4K 8.4 -> 7.5 ms, cover_image 1.31 -> 1.20 ms; 3 and 6 are slower)
 #endif
-constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT) {
-    return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > 3 ? 3 : RT_MIN_BLOCKS);
+#ifndef RT_MIN_BLOCKS_FLAT_AREA
+#define RT_MIN_BLOCKS_FLAT_AREA 3
+#endif
+constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool SPAWN = true) {
+    // the flat area-light kernels of scenes without reflective or transparent materials (no stack, no children code)
+    // fit 128 VGPRs with 5-31 spilled registers: 4 waves, C2 0.175 -> 0.159 ms (profiles/r02_nospawn.txt)
+    if (AREA && !TREE && !EXOTIC && !SPAWN) return 4;
+    return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > RT_MIN_BLOCKS_FLAT_AREA ? RT_MIN_BLOCKS_FLAT_AREA : RT_MIN_BLOCKS);
 }
 // EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
 // in f64 and the nodes that decide something are worked out again with the reference's formulas (rt_exact.h).
@@ -392,8 +398,10 @@ struct Ray64 {
     D3 o, d;
 };
 // LANE = every lane walks the hierarchy on its own (traverse above); needs TREE.
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false>
-__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT)) void render_kernel(const KParams P) {
+// SPAWN = some material is reflective or transparent; without it a path is its camera ray: no stack, no children,
+// no container pass, one round.
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true>
+__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
     static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
 #ifdef RT_ORDER
     constexpr uint32_t kOrder0 = RT_ORDER;  // experiments
@@ -425,14 +433,14 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     bool active = valid && sc.n_lights != 0;  // world.rs:44: a fold over no lights is BLACK
     V3 acc = v3(0.0f, 0.0f, 0.0f);
 
-    StackEntry stack[kStackCap];
+    StackEntry stack[SPAWN ? kStackCap : 1];
     int sp = 0;
     // The f64 copies of the path rays live in private memory, written when a node spawns them and read
     // when a node is refined: [0] the child that continues in the lane, [1 + i] the ray of stack[i];
     // `cur_slot` says where the current ray's copy is.  The camera ray (node 0) is never stored: it is
     // worked out from the pixel when a refinement asks for it.  (Indexed dynamically, so the array never
     // competes for registers.)
-    Ray64 r64[EXACT ? kStackCap + 1 : 1];
+    Ray64 r64[(EXACT && SPAWN) ? kStackCap + 1 : 1];
     uint32_t cur_slot = 0;
     auto cur64 = [&]() {
         Ray64 r;
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         auto do_select = [&](bool live, bool may_retry) {
             if (alt_prim != kNoPrim && hit_prim != kNoPrim && !(alt_t <= hit_t + amb_window(hit_t))) alt_prim = kNoPrim;  // too far behind to matter
             bool spawns = false;
-            if (!(RT_XEXP & 1) && sc.any_spawn && live && hit_prim != kNoPrim) {
+            if (SPAWN && !(RT_XEXP & 1) && sc.any_spawn && live && hit_prim != kNoPrim) {
                 const DMaterial m = sc.mats[sc.recs[hit_prim].material];
                 spawns = P.max_depth > level_of(node) && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
             }
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             // EXACT: a pattern lookup within FP32 reach of a boundary, or a local normal that was a near
             // decision (the edge of a cube), is decided by the f64 hit of the same primitive
             late = EXACT && !(RT_XEXP & 64) && !refined && (pattern_unsure(sc.pats[m.pattern], h.q + h.dq, h.eq) || h.edge);
-            need_n = depth > 0u && m.transparency > 0.0f;
+            need_n = SPAWN && depth > 0u && m.transparency > 0.0f;
             m_ior = m.ior;
             // the reference looks the pattern up once per light (material.rs:127); Solid costs nothing
             if (STATS) c_shaded++, c_pattern += (sc.pats[m.pattern].type != PAT_SOLID) ? sc.n_lights : 0u;
@@ -646,8 +654,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             }
             // the children's f64 rays go to where the children phase below expects them: the one that
             // continues in the lane to r64[0], a refraction that waits on the stack to r64[1 + sp]
-            const bool refl = depth > 0u && !(fabsf(m.reflectivity) <= kEps);
-            bool refr = depth > 0u && !(fabsf(m.transparency) <= kEps);
+            const bool refl = SPAWN && depth > 0u && !(fabsf(m.reflectivity) <= kEps);
+            bool refr = SPAWN && depth > 0u && !(fabsf(m.transparency) <= kEps);
             D3 rd = d3(0.0, 0.0, 0.0);
             if ((RT_XEXP & 8) && refr) rd = to_d3(v3(0.1f, 0.2f, 0.3f));
             if (!(RT_XEXP & 8) && refr) {  // world.rs:109-130 with the f64 indices of the records the container pass named
@@ -1062,8 +1070,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const DMaterial m = sc.mats[mi];
             m_reflectivity = m.reflectivity, m_transparency = m.transparency;
         }
-        bool want_refl = has_hit && depth > 0u && !(fabsf(m_reflectivity) <= kEps);
-        bool want_refr = has_hit && depth > 0u && !(fabsf(m_transparency) <= kEps);
+        bool want_refl = SPAWN && has_hit && depth > 0u && !(fabsf(m_reflectivity) <= kEps);
+        bool want_refr = SPAWN && has_hit && depth > 0u && !(fabsf(m_transparency) <= kEps);
         const bool use_schlick = has_hit && (m_reflectivity * m_transparency) > 0.0f;
         V3 rdir = v3(0.0f, 0.0f, 0.0f);
         const bool chain = EXACT && refined && !(RT_XEXP & 2);  // the children's f64 rays wait in r64[]
