@@ -85,8 +85,8 @@ N_CU, N_SIMD, CLOCK_HZ = 256, 4, 2.4e9  # MI355X_MICROARCH.md
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # (a frame is 0.16 ms: 20 steps end before the clocks have settled)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="striped_sphere_multiple_lights", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
