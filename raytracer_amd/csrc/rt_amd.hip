@@ -207,6 +207,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
 #define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, true, false, X, L, true>
 #elif defined(RT_EXP_ONLY_FLAT_AREA)  // (the headline's kernels only)
 #define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, false, true, X, false, P>
+#elif defined(RT_EXP_ONLY_TREE_AREA)  // (cover_image_area's kernels only)
+#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, true, true, X, false, true>
 #else
 #define RT_K(S, E, T, A, X, L, P) render_kernel<S, E, T, A, X, (T) && (L), (P) || ((T) && (L))>
 #endif

@@ -384,3 +384,25 @@ def test_tile_order_feedback_changes_the_schedule_not_the_image():
     assert np.array_equal(again, first)
     rows = np.concatenate([np.arange(b * 8, b * 8 + 8) for b in range(1, 72, 2)])  # bands 1, 3, 5, ... of 8 rows
     assert np.array_equal(band, first[rows])
+
+
+def test_lane_mode_and_union_walks_render_the_same_frame(monkeypatch):
+    """The hierarchy kernels exist twice: the wave walks the record stream as one (scalar loads), or every lane walks
+    the direction-ordered compact streams on its own (rt_kernel.h LANE).  rt_scene_create picks one per scene;
+    RT_AMD_LANE forces it.  Both must meet the oracle's golden frame at the same bar, and agree with each other
+    except where a near-tie is settled differently (counted)."""
+    name = "multiple_glass_and_metallic_spheres"
+    g = np.load(os.path.join(GOLDEN, "images.npz"))[name]  # 96x54, centre jitter, f64 oracle
+    frames = {}
+    for lane in ("0", "1"):
+        monkeypatch.setenv("RT_AMD_LANE", lane)
+        ex = ExampleScene(name, 96, 54)
+        sc = Scene(ex.scene_desc, 0)
+        assert ("true" if lane == "1" else "false") == sc.kernel_name(ex.camera_desc).split(",")[5].strip()
+        frames[lane], _ = sc.render(ex.camera_desc, RtOptions())
+        sc.close()
+    monkeypatch.delenv("RT_AMD_LANE")
+    differ = int((np.abs(frames["0"] - frames["1"]) > 1e-4).any(axis=-1).sum())
+    assert differ <= 1, differ
+    for lane, img in frames.items():
+        assert img.shape == g.shape and int((np.abs(img - g) > 1e-4).any(axis=-1).sum()) <= 1, lane
