@@ -11,7 +11,7 @@ CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -Wall -Wextra -Wno-unused-parameter -f
 all: product oracle testhelpers
 product: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_scenes.so
 
-$(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kernel.h raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
+$(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kernel.h raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -Wl,-Bsymbolic raytracer_amd/csrc/rt_amd.hip -o $@
 
@@ -22,7 +22,7 @@ oracle:
 	$(MAKE) -C oracle
 
 testhelpers: tests/cpp/_build/libhostsim.so
-tests/cpp/_build/libhostsim.so: tests/cpp/hostsim.cpp raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
+tests/cpp/_build/libhostsim.so: tests/cpp/hostsim.cpp raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
 	@mkdir -p tests/cpp/_build
 	# -Bsymbolic: the simulator must run ITS OWN copies of the inline functions of rt_math.h / rt_pack.h,
 	# not the ones exported by the product library that the same test process has loaded (RTLD_GLOBAL)
