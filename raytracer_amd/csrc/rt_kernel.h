@@ -850,7 +850,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 // reference's order (material.rs:133-136).
                 const unsigned long long summing = wave_ballot(shades) & ~behind_mask;
                 const uint32_t n_summing = static_cast<uint32_t>(__popcll(summing));
-                if (AREA && n_summing != 0u && n_summing <= RT_SHARED_PHONG_MAX && cells >= 16u && !(RT_EXP & 16384)) {
+                // (only kernels with path code: without children no wave is down to a few deep-path points, and the headline
+                // kernel is 2.5 % faster without this branch, 0.158 -> 0.154 ms)
+                if (AREA && SPAWN && n_summing != 0u && n_summing <= RT_SHARED_PHONG_MAX && cells >= 16u && !(RT_EXP & 16384)) {
                     // Few points in the wave (deep glass paths): the lanes share them out.  Each point
                     // gets 64 / 2^ceil(log2 n) lanes, each of which sums a run of its cells from the
                     // point's parked data (an LDS broadcast); a butterfly adds the runs up.
