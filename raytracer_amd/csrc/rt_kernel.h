@@ -389,7 +389,10 @@ __device__ __forceinline__ bool pixel_of_lane(const KParams& P, uint32_t order, 
 constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool SPAWN = true) {
     // the flat area-light kernels of scenes without reflective or transparent materials (no stack, no children code)
     // fit 128 VGPRs with 5-31 spilled registers: 4 waves, C2 0.175 -> 0.159 ms (profiles/r02_nospawn.txt)
-    if (AREA && !TREE && !EXOTIC && !SPAWN) return 4;
+#ifndef RT_MIN_BLOCKS_NOSPAWN
+#define RT_MIN_BLOCKS_NOSPAWN 4
+#endif
+    if (AREA && !TREE && !EXOTIC && !SPAWN) return RT_MIN_BLOCKS_NOSPAWN;
     return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > RT_MIN_BLOCKS_FLAT_AREA ? RT_MIN_BLOCKS_FLAT_AREA : RT_MIN_BLOCKS);
 }
 // EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
