@@ -435,6 +435,17 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     uint32_t node = 0;
     bool active = valid && sc.n_lights != 0;  // world.rs:44: a fold over no lights is BLACK
     V3 acc = v3(0.0f, 0.0f, 0.0f);
+    // Ray stealing (kernels with path code): a lane whose pixel is finished takes over a waiting ray of another lane
+    // of its wave (end of the path loop).  A lane then works for the pixel `pix` of another lane, so the colour of
+    // a pixel is summed in LDS (rows 3..5 of the park area, indexed by the pixel's lane) instead of a register.
+#ifndef RT_STEAL
+#define RT_STEAL 1
+#endif
+    // Only the lane-mode kernels: in a union walk the mixed depths of stolen rays widen what the wave walks together
+    // (cover_image 1.20 -> 1.65 ms with stealing), in lane mode every ray walks alone anyway (profiles/r02_ray_stealing.txt).
+    constexpr bool kSteal = SPAWN && LANE && RT_STEAL != 0;
+    static_assert(!kSteal || kBlockThreads == 64, "ray stealing exchanges through the wave's own park rows");
+    uint32_t pix = lane;
 
     StackEntry stack[SPAWN ? kStackCap : 1];
     int sp = 0;
@@ -466,6 +477,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     __shared__ float s_park[(AREA ? 35 : 24) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
+    if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
+    float* const pixel_sum = s_park + (threadIdx.x & ~63u);  // + (3 + channel) * kBlockThreads + pix
 
     unsigned long long c_primary = active ? 1ull : 0ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0,
                        c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0, c_refined = 0;
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // shading loops need every register they can get at 4 waves/SIMD, and a value parked here
         // costs no memory traffic, unlike a compiler spill to scratch.
         park[0 * kBlockThreads] = w.x, park[1 * kBlockThreads] = w.y, park[2 * kBlockThreads] = w.z;
-        park[3 * kBlockThreads] = acc.x, park[4 * kBlockThreads] = acc.y, park[5 * kBlockThreads] = acc.z;
+        if (!kSteal) park[3 * kBlockThreads] = acc.x, park[4 * kBlockThreads] = acc.y, park[5 * kBlockThreads] = acc.z;
         park[6 * kBlockThreads] = n1, park[7 * kBlockThreads] = n2;
         park[8 * kBlockThreads] = pc.x, park[9 * kBlockThreads] = pc.y, park[10 * kBlockThreads] = pc.z;
         park[11 * kBlockThreads] = m_ambient, park[12 * kBlockThreads] = m_diffuse, park[13 * kBlockThreads] = m_specular;
@@ -1061,12 +1074,21 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             }
         }
         w = v3(park[0 * kBlockThreads], park[1 * kBlockThreads], park[2 * kBlockThreads]);
-        acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
+        if (!kSteal) acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
         n1 = park[6 * kBlockThreads], n2 = park[7 * kBlockThreads];
         nrm = ld3(17);
         if (AREA) over = ld3(24), hq = ld3(27), hdq = ld3(30), hit_prim = __float_as_uint(park[33 * kBlockThreads]);
         const V3 eye = ld3(20);
-        if (has_hit) acc = acc + w * v3(park[14 * kBlockThreads], park[15 * kBlockThreads], park[16 * kBlockThreads]);
+        if (has_hit) {
+            const V3 add = w * v3(park[14 * kBlockThreads], park[15 * kBlockThreads], park[16 * kBlockThreads]);
+            if (kSteal) {  // (LDS float add; lanes of one instruction are served in lane order: the sum is reproducible)
+                atomicAdd(pixel_sum + 3 * kBlockThreads + pix, add.x);
+                atomicAdd(pixel_sum + 4 * kBlockThreads + pix, add.y);
+                atomicAdd(pixel_sum + 5 * kBlockThreads + pix, add.z);
+            } else {
+                acc = acc + add;
+            }
+        }
 
         RT_TICK(3)
         // ---------------------------------------------------------------- children (world.rs:59-69,94-133)
@@ -1135,6 +1157,68 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 active = false;
             }
         }
+        if (kSteal) {
+            // Idle lanes (pixel finished, or outside the image) take the newest waiting ray of lanes that have one:
+            // the k-th idle lane from the k-th such lane, through the park area (rows 6.. are dead here).  A round
+            // costs a wave the same with 5 busy lanes as with 64 — C4's rounds ran 43 % full — so the rounds of a
+            // tile go from its deepest pixel's node count towards its total node count / 64.
+            const bool idle = !active;
+            const bool donor = active && sp > 0;
+            const unsigned long long m_idle = wave_ballot(idle), m_donor = wave_ballot(donor);
+            const uint32_t n_idle = static_cast<uint32_t>(__popcll(m_idle)), n_donor = static_cast<uint32_t>(__popcll(m_donor));
+            const uint32_t n_pairs = n_idle < n_donor ? n_idle : n_donor;
+            if (n_pairs != 0u) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t r_idle = static_cast<uint32_t>(__popcll(m_idle & below)), r_donor = static_cast<uint32_t>(__popcll(m_donor & below));
+                float* const ex = s_park + (threadIdx.x & ~63u) + 6 * kBlockThreads;  // field f of pair r at ex[f * 32 + r]
+                auto put = [&](int f, uint32_t r, float v) { ex[f * 32 + static_cast<int>(r)] = v; };
+                auto get = [&](int f, uint32_t r) { return ex[f * 32 + static_cast<int>(r)]; };
+                if (donor && r_donor < n_pairs) {
+                    const StackEntry e = stack[--sp];  // (the newest; the oldest — a ring stack — measured the same)
+                    const float f[19] = {e.o.x, e.o.y, e.o.z, e.d.x, e.d.y, e.d.z, e.w.x, e.w.y, e.w.z, e.q.x, e.q.y, e.q.z, e.dq.x, e.dq.y, e.dq.z,
+                                         __uint_as_float(e.self), __uint_as_float(e.node), __uint_as_float(pix),
+                                         AREA ? park[34 * kBlockThreads] : 0.0f};
+                    for (int k = 0; k < 19; ++k) put(k, r_donor, f[k]);
+                    if (EXACT) {
+                        const Ray64 r = r64[1 + sp];
+                        const double d6[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
+                        for (int k = 0; k < 6; ++k) {
+                            const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d6[k]));
+                            put(19 + 2 * k, r_donor, __uint_as_float(static_cast<uint32_t>(b)));
+                            put(20 + 2 * k, r_donor, __uint_as_float(static_cast<uint32_t>(b >> 32)));
+                        }
+                    }
+                }
+                // (same wave: LDS operations complete in order; the fence keeps the compiler from moving the reads up)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (idle && r_idle < n_pairs) {
+                    cur.o = v3(get(0, r_idle), get(1, r_idle), get(2, r_idle));
+                    cur.d = v3(get(3, r_idle), get(4, r_idle), get(5, r_idle));
+                    w = v3(get(6, r_idle), get(7, r_idle), get(8, r_idle));
+                    cur.q = v3(get(9, r_idle), get(10, r_idle), get(11, r_idle));
+                    cur.dq = v3(get(12, r_idle), get(13, r_idle), get(14, r_idle));
+                    cur.self = __float_as_uint(get(15, r_idle));
+                    node = __float_as_uint(get(16, r_idle));
+                    pix = __float_as_uint(get(17, r_idle));
+                    const float key = get(18, r_idle);
+                    if (EXACT) {
+                        double d6[6];
+                        for (int k = 0; k < 6; ++k) {
+                            const unsigned long long b = static_cast<unsigned long long>(__float_as_uint(get(19 + 2 * k, r_idle))) |
+                                                         (static_cast<unsigned long long>(__float_as_uint(get(20 + 2 * k, r_idle))) << 32);
+                            d6[k] = __longlong_as_double(static_cast<long long>(b));
+                        }
+                        r64[0].o = d3(d6[0], d6[1], d6[2]), r64[0].d = d3(d6[3], d6[4], d6[5]);
+                        cur_slot = 0;
+                    }
+                    if (AREA) park[34 * kBlockThreads] = key;
+                    active = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         RT_TICK(4)
     }
 
@@ -1146,6 +1230,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         uint32_t ox, oyl, ogy;
         if (pixel_of_lane(P, kOrder, wave, lane_again, ox, oyl, ogy)) {
             float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
+            if (kSteal) acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }
