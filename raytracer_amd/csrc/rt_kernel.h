@@ -1162,12 +1162,18 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             // the k-th idle lane from the k-th such lane, through the park area (rows 6.. are dead here).  A round
             // costs a wave the same with 5 busy lanes as with 64 — C4's rounds ran 43 % full — so the rounds of a
             // tile go from its deepest pixel's node count towards its total node count / 64.
+#ifndef RT_STEAL_PASSES
+#define RT_STEAL_PASSES 3  // a lane with several waiting rays serves several idle lanes in one round
+#endif
+#pragma unroll 1
+            for (int pass = 0; pass < RT_STEAL_PASSES; ++pass) {
             const bool idle = !active;
             const bool donor = active && sp > 0;
             const unsigned long long m_idle = wave_ballot(idle), m_donor = wave_ballot(donor);
             const uint32_t n_idle = static_cast<uint32_t>(__popcll(m_idle)), n_donor = static_cast<uint32_t>(__popcll(m_donor));
             const uint32_t n_pairs = n_idle < n_donor ? n_idle : n_donor;
-            if (n_pairs != 0u) {
+            if (n_pairs == 0u) break;
+            {
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t r_idle = static_cast<uint32_t>(__popcll(m_idle & below)), r_donor = static_cast<uint32_t>(__popcll(m_donor & below));
                 float* const ex = s_park + (threadIdx.x & ~63u) + 6 * kBlockThreads;  // field f of pair r at ex[f * 32 + r]
@@ -1217,6 +1223,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
+            }
             }
         }
         RT_TICK(4)
