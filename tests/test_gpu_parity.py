@@ -406,3 +406,27 @@ def test_lane_mode_and_union_walks_render_the_same_frame(monkeypatch):
     assert differ <= 1, differ
     for lane, img in frames.items():
         assert img.shape == g.shape and int((np.abs(img - g) > 1e-4).any(axis=-1).sum()) <= 1, lane
+
+
+def test_scene_variant_names_the_kernel_family():
+    """rt_scene_variant: which render_kernel<...> instantiation a scene runs (bench.py's roofline.kernel, profiling)."""
+    expect = {  # (EXOTIC, TREE, AREA, LANE, SPAWN)
+        "striped_sphere_multiple_lights": ("false", "false", "true", "false", "false"),       # flat, area lights, no mirror or glass
+        "checkered_walls_metallic_sphere": ("false", "false", "true", "false", "true"),
+        "multiple_glass_and_metallic_spheres": ("false", "true", "false", "true", "true"),    # long hierarchy with glass: lane mode
+        "cover_image": ("false", "true", "false", "false", "true"),
+        "obj_mesh": ("true", "true", "false", "false", None),
+    }
+    for name, (exotic, tree, area, lane, spawn) in expect.items():
+        ex = ExampleScene(name, 64, 36)
+        sc = Scene(ex.scene_desc, 0)
+        f32 = RtOptions()
+        f32.flags = capi.RT_FLAG_F32_ONLY
+        a = [x.strip(" >") for x in sc.kernel_name(ex.camera_desc).split("<")[1].split(",")]
+        b = [x.strip(" >") for x in sc.kernel_name(ex.camera_desc, f32, stats=True).split("<")[1].split(",")]
+        sc.close()
+        assert a[0] == "false" and b[0] == "true"          # counters
+        assert a[4] == "true" and b[4] == "false"          # f64 chain on by default, off with RT_FLAG_F32_ONLY
+        assert (a[1], a[2], a[3], a[5]) == (exotic, tree, area, lane), (name, a)
+        if spawn is not None:
+            assert a[6] == spawn, (name, a)
