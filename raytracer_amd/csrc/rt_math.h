@@ -333,8 +333,9 @@ RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float 
     float a = fmaf(d.x, d.x, d.z * d.z);
     if (!approx(a, 0.0f)) {
         float t0, t1;
-        if (self && fabsf(fmaf(q.x, q.x, q.z * q.z) - 1.0f) < 1e-3f) {
-            // origin on the wall: q_x^2 + q_z^2 == 1 exactly, c has no cancellation
+        if (self && q.y != ymin && q.y != ymax && fabsf(fmaf(q.x, q.x, q.z * q.z) - 1.0f) < 1e-5f) {
+            // origin on the wall (prepare_hit normalised q there; a point it snapped onto a CAP has q.y == ymin / ymax
+            // and may lie anywhere inside the rim, 1e-4 from it included): q_x^2 + q_z^2 == 1, c has no cancellation
             float h = fmaf(os.x, d.x, os.z * d.z);  // b/2
             float c = fmaf(2.0f, fmaf(q.x, dq.x, q.z * dq.z), fmaf(dq.x, dq.x, dq.z * dq.z));
             if (!on_surface_roots(a, h, c, t0, t1)) return;  // cylinder.rs:140-142 returns WITHOUT testing the caps
@@ -807,6 +808,9 @@ struct HitInfo {
     bool edge;   // the local normal was a near decision: the edge of a cube, the rim of a capped cylinder
 };
 
+#ifndef RT_DIR_ERR
+#define RT_DIR_ERR 1.5e-7f  // bound on the absolute FP32 error of a component of a unit ray direction (prepare_hit)
+#endif
 template <bool EXOTIC = true>
 RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, bool self, float t, float hu, float hv,
                           bool want_eq = true) {  // want_eq = false: h.eq is not needed (solid pattern, FP32-only path)
@@ -835,7 +839,10 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             if (want_eq) {  // t = -o.y / d.y is ill-conditioned for a grazing ray: its error moves the point along the ray
                 const float a = fabsf(p.inv[4] * ray.o.x) + fabsf(p.inv[5] * ray.o.y) + fabsf(p.inv[6] * ray.o.z) + fabsf(p.inv[7]);
                 const float b = fabsf(p.inv[4] * ray.d.x) + fabsf(p.inv[5] * ray.d.y) + fabsf(p.inv[6] * ray.d.z);
-                const float dt = 2e-7f * fmaf(fabsf(t), b, a) * rcp_f(fabsf(d.y));
+                // (the FP32 direction itself is a unit vector known to an ABSOLUTE 1e-7 or so per component, whatever
+                // the size of d.y: towards the horizon that, not the rounding of the sum, is what moves t)
+                const float c = fabsf(p.inv[4]) + fabsf(p.inv[5]) + fabsf(p.inv[6]);
+                const float dt = fmaf(2e-7f, fmaf(fabsf(t), b, a), RT_DIR_ERR * fabsf(t) * c) * rcp_f(fabsf(d.y));
                 h.eq.x = fmaf(fabsf(d.x), dt, h.eq.x), h.eq.z = fmaf(fabsf(d.z), dt, h.eq.z);
             }
             h.eq.y = 0.0f;
@@ -867,7 +874,8 @@ RT_HD HitInfo prepare_hit(const DPrim& p, const DExtra* extras, const Ray& ray, 
             float top = e[1] - kEps, bot = e[0] + kEps;
             h.edge = dist > 0.99f && (fabsf(q.y - e[1]) < kGraze || fabsf(q.y - e[0]) < kGraze);
             // a cap is a plane: t = (cap - o.y) / d.y is ill-conditioned for a ray that grazes it (as for PRIM_PLANE)
-            const float cap_dt = 2e-7f * (fabsf(e[1]) + fabsf(e[0]) + fabsf(o.y) + fabsf(t * d.y)) * rcp_f(fabsf(d.y));
+            const float cap_c = fabsf(p.inv[4]) + fabsf(p.inv[5]) + fabsf(p.inv[6]);
+            const float cap_dt = fmaf(2e-7f, fabsf(e[1]) + fabsf(e[0]) + fabsf(o.y) + fabsf(t * d.y), RT_DIR_ERR * fabsf(t) * cap_c) * rcp_f(fabsf(d.y));
             if (dist < 1.0f && (approx(q.y, top) || q.y > top)) {
                 q.y = e[1];
                 h.eq.x = fmaf(fabsf(d.x), cap_dt, h.eq.x), h.eq.z = fmaf(fabsf(d.z), cap_dt, h.eq.z), h.eq.y = 0.0f;
