@@ -618,6 +618,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // ---------------------------------------------------------------- containers (intersection.rs:71-103)
         if (!(RT_EXP & 64) && wave_any(need_n)) {
             ContainerScan cs;
+            cs.order = TREE ? sc.order : nullptr;
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     return true;
                 });
             if (need_n) {
-                cs.finish(m_ior, n1, n2);
-                if (EXACT) cs.finish_prims(hit_prim, n1_prim, n2_prim);
+                cs.finish(m_ior, ord_hit, n1, n2);
+                if (EXACT) cs.finish_prims(hit_prim, ord_hit, n1_prim, n2_prim);
                 if (STATS) c_container++;
             }
         }

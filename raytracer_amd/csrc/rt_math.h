@@ -752,13 +752,34 @@ RT_HD int shaft_side_of_surface(const Shaft& s, V3 n, const DLight& l) {
 // before the hit toggles, n2 after.  Equivalent, per primitive: it is in the list at the hit iff an
 // ODD number of its intersections precede the hit, and the list's last entry is the contained
 // primitive whose latest preceding crossing has the largest t.
+#ifndef RT_CONTAINER_TIES
+#define RT_CONTAINER_TIES 1  // experiments: 0 = crossings of different primitives ordered by FP32 t alone (round 1),
+                             // 2 = the best container's order key fetched in the tie case instead of carried (slower)
+#endif
 struct ContainerScan {
     float best_t = -INFINITY, best_ior = 1.0f, hit_last = -INFINITY;
     bool have_best = false, hit_in = false;
-    uint32_t best_prim = kNoPrim;  // the record best_ior came from (the exact chain reads its f64 index)
+    uint32_t best_prim = kNoPrim;     // the record best_ior came from (its order key; the exact chain reads its f64 index)
+    const uint32_t* order = nullptr;  // record -> world.objects position (null: the records ARE in that order)
+#if RT_CONTAINER_TIES == 1
+    uint32_t best_ord = 0u;
+#endif
 
+    // Is crossing (t, ord) later in the reference's sorted list than the best one so far?  Crossings within the
+    // tie window of each other keep world.objects order (a stable sort under the approximate comparison): the
+    // bottom of a glass cube standing ON the floor plane and the plane itself, seen from a point on that floor.
+    RT_HD bool later_than_best(float t, uint32_t ord) const {
+#if RT_CONTAINER_TIES == 0
+        return t > best_t;
+#elif RT_CONTAINER_TIES == 1
+        return (fabsf(t - best_t) <= tie_window(best_t)) ? (ord > best_ord) : (t > best_t);
+#else
+        if (fabsf(t - best_t) <= tie_window(best_t)) return ord > (order ? order[best_prim] : best_prim);  // (rare: the key is fetched here)
+        return t > best_t;
+#endif
+    }
     // ord / ord_hit: world.objects positions of this primitive and of the hit one
-    RT_HD void add(const Hits& h, bool is_hit_prim, uint32_t ord, float ior, uint32_t ord_hit, float t_hit, uint32_t prim = kNoPrim) {
+    RT_HD void add(const Hits& h, bool is_hit_prim, uint32_t ord, float ior, uint32_t ord_hit, float t_hit, uint32_t prim) {
         int skipk = -1;  // the hit itself = the hit primitive's intersection closest to t_hit
         float bd = INFINITY;
         for (int k = 0; k < 4; ++k)
@@ -769,13 +790,19 @@ struct ContainerScan {
             if (k != skipk && h.t[k] == h.t[k] && precedes_hit(h.t[k], t_hit, ord, ord_hit)) ++cnt, last = fmaxf(last, h.t[k]);
         if (cnt & 1) {
             if (is_hit_prim) hit_in = true, hit_last = last;
-            else if (!have_best || last > best_t) have_best = true, best_t = last, best_ior = ior, best_prim = prim;
+            else if (!have_best || later_than_best(last, ord)) {
+                have_best = true, best_t = last, best_ior = ior, best_prim = prim;
+#if RT_CONTAINER_TIES == 1
+                best_ord = ord;
+#endif
+            }
         }
     }
-    RT_HD void finish(float hit_ior, float& n1, float& n2) const {
+    RT_HD bool hit_is_last(uint32_t ord_hit) const { return !have_best || later_than_best(hit_last, ord_hit); }
+    RT_HD void finish(float hit_ior, uint32_t ord_hit, float& n1, float& n2) const {
         const float excl = have_best ? best_ior : 1.0f;
         if (hit_in) {
-            n1 = (!have_best || hit_last > best_t) ? hit_ior : best_ior;
+            n1 = hit_is_last(ord_hit) ? hit_ior : best_ior;
             n2 = excl;
         } else {
             n1 = excl;
@@ -783,10 +810,10 @@ struct ContainerScan {
         }
     }
     // The same answer as record indices: kNoPrim = outside everything (index 1.0), `hit_prim` = the hit one.
-    RT_HD void finish_prims(uint32_t hit_prim, uint32_t& p1, uint32_t& p2) const {
+    RT_HD void finish_prims(uint32_t hit_prim, uint32_t ord_hit, uint32_t& p1, uint32_t& p2) const {
         const uint32_t excl = have_best ? best_prim : kNoPrim;
         if (hit_in) {
-            p1 = (!have_best || hit_last > best_t) ? hit_prim : best_prim;
+            p1 = hit_is_last(ord_hit) ? hit_prim : best_prim;
             p2 = excl;
         } else {
             p1 = excl;

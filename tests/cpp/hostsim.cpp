@@ -109,6 +109,7 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
 void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2, uint32_t& n1_prim,
                 uint32_t& n2_prim) {
     ContainerScan cs;
+    cs.order = s.ps.order.data();
     const V3 hp = madd(ray.d, t_hit, ray.o);
     const float hm = container_margin(t_hit, hp);
     const V3 inv_d = inv_dir(ray.d);
@@ -126,8 +127,8 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
         intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot & 3] = t, any = true; });
         if (any && gated_in(s, prim, ray)) cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit, prim);
     }
-    cs.finish(hit_ior, n1, n2);
-    cs.finish_prims(hit_prim, n1_prim, n2_prim);
+    cs.finish(hit_ior, s.ps.order[hit_prim], n1, n2);
+    cs.finish_prims(hit_prim, s.ps.order[hit_prim], n1_prim, n2_prim);
 }
 
 // ---------------------------------------------------------------------------------------------
