@@ -217,6 +217,22 @@ RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro,
     return h;
 }
 
+// The f64 crossings of one primitive handed to the FP32 container scan (rt_math.h ContainerScan): each is placed
+// relative to the f64 hit by the reference's rule (|t - t_hit| <= 1e-5 is a tie) and written so that the scan's own
+// FP32 rule repeats that decision: a tie becomes t_hit itself, the others keep their value but stay outside its window.
+RT_HD Hits xplace(const XHits& x, double t64, float t_hit) {
+    Hits h;
+    const float w = 2.0f * tie_window(t_hit);
+    for (int k = 0; k < 4; ++k) {
+        const double t = x.t[k];
+        if (t == kAbsent) h.t[k] = RT_NOHIT;
+        else if (fabs(t - t64) <= kEpsD) h.t[k] = t_hit;
+        else if (t < t64) h.t[k] = fminf(static_cast<float>(t), t_hit - w);
+        else h.t[k] = fmaxf(static_cast<float>(t), t_hit + w);
+    }
+    return h;
+}
+
 // Intersection::sort + hit (intersection.rs:105-120) over the intersections of up to two candidate
 // primitives, entered in world.objects order: approximate comparator, insertion sort (stable), the
 // first t > 0.0 wins.  K slots per primitive (absent = +inf, which sorts last and never wins); every index

@@ -403,6 +403,9 @@ struct Ray64 {
 // LANE = every lane walks the hierarchy on its own (traverse above); needs TREE.
 // SPAWN = some material is reflective or transparent; without it a path is its camera ray: no stack, no children,
 // no container pass, one round.
+#ifndef RT_CONTAINER_F64
+#define RT_CONTAINER_F64 1  // experiments: 0 = the container scan never asks f64 (before the stress fuzz family)
+#endif
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true>
 __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
     static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
@@ -619,6 +622,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         if (!(RT_EXP & 64) && wave_any(need_n)) {
             ContainerScan cs;
             cs.order = TREE ? sc.order : nullptr;
+            [[maybe_unused]] uint32_t amb_prim = kNoPrim;
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
@@ -635,9 +639,22 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     bool any = false;
                     intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot & 3] = t, any = true; });
                     if (any && (TREE && sc.has_gates)) any = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);
+                    // EXACT: the first primitive with a crossing FP32 cannot order against the hit waits for f64
+                    // (if constexpr: the other kernels' visitor must not even capture what this reads)
+                    if constexpr (EXACT && RT_CONTAINER_F64 != 0) {
+                        if (any && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(hh, hit_t)) amb_prim = prim, any = false;
+                    }
                     if (any) cs.add(hh, prim == hit_prim, TREE ? sc.order[prim] : prim, p.ior, ord_hit, hit_t, prim);
                     return true;
                 });
+            if constexpr (EXACT && RT_CONTAINER_F64 != 0) {  // rare: a face shared with the hit one, a body touching it
+                if (wave_any(amb_prim != kNoPrim) && amb_prim != kNoPrim) {
+                    const Ray64 r = cur64();
+                    const DPrim pa = sc.recs[amb_prim];
+                    const XHits hx = xintersect<EXOTIC>(pa.type, sc.xprims[amb_prim].inv, sc.xextras[pa.extra].f, r.o, r.d);
+                    cs.add(xplace(hx, t64, hit_t), false, TREE ? sc.order[amb_prim] : amb_prim, pa.ior, ord_hit, hit_t, amb_prim);
+                }
+            }
             if (need_n) {
                 cs.finish(m_ior, ord_hit, n1, n2);
                 if (EXACT) cs.finish_prims(hit_prim, ord_hit, n1_prim, n2_prim);

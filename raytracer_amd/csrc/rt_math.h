@@ -752,6 +752,14 @@ RT_HD int shaft_side_of_surface(const Shaft& s, V3 n, const DLight& l) {
 // before the hit toggles, n2 after.  Equivalent, per primitive: it is in the list at the hit iff an
 // ODD number of its intersections precede the hit, and the list's last entry is the contained
 // primitive whose latest preceding crossing has the largest t.
+// EXACT: a crossing of ANOTHER primitive this close to the hit is more than FP32 can order against the reference's
+// 1e-5 rule: a ray that grazes the face two stacked cubes share gets t = (1 - o_k) / d_k to 1e-7 / |d_k| only
+// (1.2e-5 at t = 0.58 in random_stress:148).  The kernel then places that primitive's crossings in f64 (rt_exact.h).
+RT_HD float container_amb_window(float t) { return 16.0f * tie_window(t); }
+RT_HD bool crossing_near_hit(const Hits& h, float t_hit) {
+    const float w = container_amb_window(t_hit);
+    return fabsf(h.t[0] - t_hit) <= w || fabsf(h.t[1] - t_hit) <= w || fabsf(h.t[2] - t_hit) <= w || fabsf(h.t[3] - t_hit) <= w;  // NaN: false
+}
 #ifndef RT_CONTAINER_TIES
 #define RT_CONTAINER_TIES 1  // experiments: 0 = crossings of different primitives ordered by FP32 t alone (round 1),
                              // 2 = the best container's order key fetched in the tie case instead of carried (slower)
