@@ -317,6 +317,8 @@ RT_HD bool xselect(const XHits& ha, uint32_t prim_a, uint32_t type_a, const XHit
 // intersection.rs:40-69 + shape.rs:83-96,118-137 + the shapes' local normals
 struct XHit {
     D3 point, normal, eye, reflectv, over, under;
+    D3 qobj;    // the hit point in object space; the coordinate a face / cap / plane fixes is set exactly
+    int qround;  // what is left for FP32 (xsnap_q): 1 = scale onto the unit sphere, 2 = x, z onto the unit circle
     bool inside;
 };
 template <bool EXOTIC = true>
@@ -325,25 +327,32 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
     h.point = ro + rd * t;  // ray.rs:13-15
     h.eye = xneg(rd);
     const D3 p = xpoint(inv, h.point);
+    h.qobj = p, h.qround = 0;
     D3 nobj = d3(0.0, 1.0, 0.0);
     switch (type) {
-        case PRIM_SPHERE: nobj = p - d3(0.0, 0.0, 0.0); break;  // sphere.rs:74-76
-        case PRIM_PLANE: nobj = d3(0.0, 1.0, 0.0); break;       // plane.rs:53-55
+        case PRIM_SPHERE:  // sphere.rs:74-76
+            nobj = p - d3(0.0, 0.0, 0.0);
+            h.qround = 1;
+            break;
+        case PRIM_PLANE:  // plane.rs:53-55
+            nobj = d3(0.0, 1.0, 0.0);
+            h.qobj = d3(p.x, 0.0, p.z);
+            break;
         case PRIM_CUBE: {                                       // cube.rs:125-141
             const double ax = fabs(p.x), ay = fabs(p.y), az = fabs(p.z);
             double mc = (ax > ay) ? ax : ay;  // max_by with the exact comparison: the largest value
             mc = (mc > az) ? mc : az;
-            if (xapprox(mc, ax)) nobj = d3(p.x, 0.0, 0.0);
-            else if (xapprox(mc, ay)) nobj = d3(0.0, p.y, 0.0);
-            else nobj = d3(0.0, 0.0, p.z);
+            if (xapprox(mc, ax)) nobj = d3(p.x, 0.0, 0.0), h.qobj.x = p.x < 0.0 ? -1.0 : 1.0;
+            else if (xapprox(mc, ay)) nobj = d3(0.0, p.y, 0.0), h.qobj.y = p.y < 0.0 ? -1.0 : 1.0;
+            else nobj = d3(0.0, 0.0, p.z), h.qobj.z = p.z < 0.0 ? -1.0 : 1.0;
             break;
         }
         case PRIM_CYLINDER: {  // cylinder.rs:172-184
             if (!EXOTIC) break;
             const double dist = p.x * p.x + p.z * p.z;
-            if (dist < 1.0 && xge(p.y, e[1] - kEpsD)) nobj = d3(0.0, 1.0, 0.0);
-            else if (dist < 1.0 && xle(p.y, e[0] + kEpsD)) nobj = d3(0.0, -1.0, 0.0);
-            else nobj = d3(p.x, 0.0, p.z);
+            if (dist < 1.0 && xge(p.y, e[1] - kEpsD)) nobj = d3(0.0, 1.0, 0.0), h.qobj.y = e[1];
+            else if (dist < 1.0 && xle(p.y, e[0] + kEpsD)) nobj = d3(0.0, -1.0, 0.0), h.qobj.y = e[0];
+            else nobj = d3(p.x, 0.0, p.z), h.qround = 2;
             break;
         }
         case PRIM_TRIANGLE:  // triangle.rs:135-137
@@ -365,6 +374,18 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
     h.over = h.point + n * kEpsD;
     h.under = h.point - n * kEpsD;
     return h;
+}
+
+// The object-space point the rays leaving a refined hit stand on (Ray::q): the f64 point rounded to FP32 and put
+// onto the surface the way rt_math.h prepare_hit does it (a unit vector to FP32 rounding; exact face coordinates).
+RT_HD V3 xsnap_q(const XHit& h) {
+    V3 q = to_v3(h.qobj);
+    if (h.qround == 1) q = normalize(q);
+    else if (h.qround == 2) {
+        const float s = rsq_f(fmaf(q.x, q.x, q.z * q.z));
+        q.x *= s, q.z *= s;
+    }
+    return q;
 }
 
 // `|f % 2| <= 1e-5` (pattern.rs:74,82,89) for an integer-valued f (a floor, or a sum of floors): |f % 2| is

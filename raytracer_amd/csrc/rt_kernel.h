@@ -403,6 +403,9 @@ struct Ray64 {
 // LANE = every lane walks the hierarchy on its own (traverse above); needs TREE.
 // SPAWN = some material is reflective or transparent; without it a path is its camera ray: no stack, no children,
 // no container pass, one round.
+#ifndef RT_XQ
+#define RT_XQ 1  // experiments: 0 = rays leaving a refined hit keep the FP32 hit's object-space point
+#endif
 #ifndef RT_CONTAINER_F64
 #define RT_CONTAINER_F64 1  // experiments: 0 = the container scan never asks f64 (before the stress fuzz family)
 #endif
@@ -679,6 +682,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
           if (refined) {
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
+            // (the rays that leave this point start at the f64 point: their "self" form must stand on the same point.  The
+            // FP32 hit point of a grazing ray is 1e-6 / |n . d| along the surface from it — 1e-4 in random_stress:162 —
+            // and a child that itself grazes a face turns a 1e-6 offset into 1e-5 of t, random_stress:33.  Costs 1.5-3 %;
+            // doing it for grazing hits only is no cheaper and misses the second case: profiles/r02_random_worlds.txt)
+            if (RT_XQ) hq = xsnap_q(xh), hdq = xform_vector(p.inv, nrm) * kEps;
             const DPattern pat = sc.pats[m.pattern];
             if (!(RT_XEXP & 4) && pat.type != PAT_SOLID) {
                 double frac;

@@ -382,6 +382,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             if (refined) {  // the reference's own hit geometry (rt_exact.h)
                 xh = xprepare(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64, t64, u64, v64);
                 over = to_v3(xh.over), h.n = to_v3(xh.normal), h.inside = xh.inside, h.p = to_v3(xh.point);
+                h.q = xsnap_q(xh), h.dq = xform_vector(p.inv, h.n) * kEps;  // (the kernel's rule: children start on the f64 point)
                 const DPattern& pat = s.ps.pats[m.pattern];
                 double frac;
                 const bool is_a = xpattern_is_a(pat.type, s.ps.xprims[hit_prim].inv, s.ps.xpats[m.pattern].inv, xh.over, frac);

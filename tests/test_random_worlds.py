@@ -23,7 +23,7 @@ sphere on a cube on the floor (tangent points), the camera inside a glass ball, 
 glass slab 0.02 thick, mirrored (negative-determinant) transforms, glass triangles sharing an edge, two mirrors
 facing each other, a tiny and a far object, two patterned planes meeting in a corner line.
 
-Round 2 found four defects of the FP32 path with these scenes, all fixed and pinned here:
+Round 2 found five defects of the FP32 path with these scenes, all fixed and pinned here:
   * patterned planes near the horizon: the error bound of the object-space hit point did not count the absolute
     error of the FP32 ray direction, so the f64 chain was not asked where it was needed (14 pixels of 442k);
   * a refracted ray that entered a closed cylinder through a cap within 1e-3 of the rim took the "origin on the
@@ -34,7 +34,10 @@ Round 2 found four defects of the FP32 path with these scenes, all fixed and pin
   * two stacked cubes, the lower one glass: a ray inside it that grazes the shared face gets the two (equal) crossings
     to 1e-7 / |d_y| only — 1.2e-5 apart at t = 0.58, outside the 1e-5 tie window, so the upper cube was taken for a
     container (9 pixels of 1.2 M).  With the f64 chain the container scan now hands the first primitive whose
-    crossing lies within 16 windows of the hit to f64 (rt_exact.h xplace); FP32 alone cannot decide it.
+    crossing lies within 16 windows of the hit to f64 (rt_exact.h xplace); FP32 alone cannot decide it;
+  * rays leaving a hit the f64 chain refined started at the f64 point but kept the FP32 hit's object-space point for
+    their "self" intersection form: for a grazing camera ray the two are 1e-4 apart along the surface, and a child
+    that grazes a shared face turns 1e-6 into 1e-5 of t (random_stress:162 and :33, 6 pixels of 3.07 M on the GPU).
 """
 import numpy as np
 import pytest
@@ -151,6 +154,22 @@ def test_grazing_the_face_two_stacked_cubes_share_is_settled_in_f64():
     ref, _, _ = H.oracle_render(name, 96, 64, jitter=1, seed=5, threads=8, rows=(24, 32))
     assert np.abs(sim[3, [32, 35, 47]] - ref[27, [32, 35, 47]]).max() <= TOL
     assert H.compare(sim, ref[24:32], TOL)["bad_pixels"] <= 1  # (30,27) is a shadow-ray edge
+
+
+def test_rays_leaving_a_refined_hit_stand_on_the_f64_point():
+    """random_stress:162 at 160x96 pixel (153, 70): a camera ray grazes a glass sphere that shares its surface with a
+    second one (sin of the angle of incidence = 1.0); the refracted ray's own exit must tie with the twin's exit
+    (n1 = n2 = 2.0), not miss it by 1e-4.  random_stress:33 pixels (85, 12..14): inside a glass cube the refracted
+    ray leaves through a face shared with the next cube."""
+    for name, x, rows in (("random_stress:162", 153, (70,)), ("random_stress:33", 85, (12, 13, 14))):
+        ex = ExampleScene(name, 160, 96)
+        o = _options()
+        band = rows[0] // 8
+        o.tile_rows, o.tile_first, o.tile_stride = 8, band, 12
+        sim = H.hostsim_render(ex, o)
+        ref, _, _ = H.oracle_render(name, 160, 96, jitter=1, seed=5, threads=8, rows=(band * 8, band * 8 + 8))
+        for y in rows:
+            assert np.abs(sim[y - band * 8, x] - ref[y, x]).max() <= TOL, (name, x, y)
 
 
 @pytest.mark.gpu
