@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--jitter-seed", type=int, default=5)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--family", default="random_world", choices=["random_world", "random_field", "random_stress"])
+    ap.add_argument("--family", default="random_world", choices=["random_world", "random_field", "random_stress", "random_mesh"])
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--classify", action="store_true")
     a = ap.parse_args()
