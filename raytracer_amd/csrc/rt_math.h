@@ -185,7 +185,13 @@ RT_HD float min_by3(float a, float b, float c) {
 RT_HD float tie_window(float t) { return kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
 // Two candidates closer than this (or a candidate this close to t = 0) are more than FP32 can order
 // against the reference's 1e-5 tie rule: the exact chain (rt_exact.h) settles them in f64.
-RT_HD float amb_window(float t) { return 4.0f * kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
+// (64 tie windows since the stress fuzz family: a ray running within 0.002 rad of a face two cubes share knows each
+// crossing to 1e-7 / |d_k| = 5e-5 only; 4 windows missed that pair, 64 cost nothing measurable — C4 6.87 vs 6.87 ms,
+// cover_image 1.22 vs 1.22, profiles/r02_random_worlds.txt)
+#ifndef RT_AMB_FACTOR
+#define RT_AMB_FACTOR 64.0f
+#endif
+RT_HD float amb_window(float t) { return RT_AMB_FACTOR * kEps * fmaxf(1.0f, 0.25f * fabsf(t)); }
 RT_HD bool closer_hit(float t, float best) { return t > 0.0f && t < best - tie_window(t); }  // best may be +inf
 // Candidates do not always arrive in world.objects order (the device walks its own hierarchy): an
 // approximately equal t is a TIE, which the caller resolves by the primitives' order keys.
