@@ -1,19 +1,36 @@
 # Builds everything in-tree (the built .so files travel to the GPU box with the source tree).
-#   make            product library + example-scene library + oracle + test helpers
+#   make -j8        product library + example-scene library + oracle + test helpers
 #   make product    raytracer_amd/_lib/librt_amd.so (HIP, gfx950) and librt_scenes.so
+# Experimental builds of the product library (scripts/exp_build.sh):
+#   make -j8 kernels LIBDIR=scratch/exp/NAME OBJDIR=scratch/exp/NAME/obj EXTRA_HIPFLAGS="-DRT_EXP=4"
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 ARCH     ?= gfx950
-LIBDIR   := raytracer_amd/_lib
-HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function
+LIBDIR   ?= raytracer_amd/_lib
+OBJDIR   ?= build/obj
+HIPCFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical
 CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -Wall -Wextra -Wno-unused-parameter -ffp-contract=off
+CSRC     := raytracer_amd/csrc
+KHEADERS := $(CSRC)/rt_kernel.h $(CSRC)/rt_math.h $(CSRC)/rt_exact.h include/rt_amd.h
+# render_kernel's instantiations, one translation unit per group (rt_kernels.hip): they compile in parallel
+KGROUPS  := 0 1 3 4 5 7
+KOBJS    := $(KGROUPS:%=$(OBJDIR)/rt_kernels_%.o)
 
 all: product oracle testhelpers
 product: $(LIBDIR)/librt_amd.so $(LIBDIR)/librt_scenes.so
+kernels: $(LIBDIR)/librt_amd.so
 
-$(LIBDIR)/librt_amd.so: raytracer_amd/csrc/rt_amd.hip raytracer_amd/csrc/rt_kernel.h raytracer_amd/csrc/rt_math.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_pack.h include/rt_amd.h
+$(OBJDIR)/rt_kernels_%.o: $(CSRC)/rt_kernels.hip $(KHEADERS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPCFLAGS) $(EXTRA_HIPFLAGS) -DRT_KGROUP=$* -c $(CSRC)/rt_kernels.hip -o $@
+
+$(OBJDIR)/rt_amd.o: $(CSRC)/rt_amd.hip $(CSRC)/rt_aux_kernels.h $(CSRC)/rt_pack.h $(KHEADERS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPCFLAGS) $(EXTRA_HIPFLAGS) -c $(CSRC)/rt_amd.hip -o $@
+
+$(LIBDIR)/librt_amd.so: $(OBJDIR)/rt_amd.o $(KOBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -Wl,-Bsymbolic raytracer_amd/csrc/rt_amd.hip -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -pthread -Wl,-Bsymbolic $^ -o $@
 
 $(LIBDIR)/librt_scenes.so: scenes/scenes_capi.cpp scenes/examples.inc include/raytracer_amd/raytracer.hpp include/raytracer_amd/png.hpp include/rt_amd.h $(LIBDIR)/librt_amd.so
 	$(CXX) $(CXXFLAGS) -shared scenes/scenes_capi.cpp -o $@ -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
@@ -29,6 +46,6 @@ tests/cpp/_build/libhostsim.so: tests/cpp/hostsim.cpp raytracer_amd/csrc/rt_math
 	$(CXX) $(CXXFLAGS) -shared -Wl,-Bsymbolic tests/cpp/hostsim.cpp -o $@
 
 clean:
-	rm -rf $(LIBDIR) tests/cpp/_build
+	rm -rf $(LIBDIR) $(OBJDIR) tests/cpp/_build
 	$(MAKE) -C oracle clean
-.PHONY: all product oracle testhelpers clean
+.PHONY: all product kernels oracle testhelpers clean

@@ -14,10 +14,21 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "rt_aux_kernels.h"
 #include "rt_kernel.h"
 #include "rt_pack.h"
 
 using namespace rtk;
+
+namespace rtk {  // rt_kernels.hip, one translation unit per group
+using KernelFn = void (*)(const KParams);
+KernelFn kernel_group_0(int variant);
+KernelFn kernel_group_1(int variant);
+KernelFn kernel_group_3(int variant);
+KernelFn kernel_group_4(int variant);
+KernelFn kernel_group_5(int variant);
+KernelFn kernel_group_7(int variant);
+}  // namespace rtk
 
 namespace {
 
@@ -199,36 +210,23 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     }
     const uint32_t tiles_per_block = rtk::kBlockThreads / 64u;
     const uint32_t blocks = (P.n_tiles + tiles_per_block - 1u) / tiles_per_block;  // one wave per tile
-    // 80 instantiations (48 + the 32 union-walk kernels once more without path code): counters x cylinder/triangle code x hierarchy/gate code x area-light code x f64 chain
-    // (x lane-mode walks for the hierarchy variants)
+    // 80 instantiations, compiled group by group (rt_kernels.hip): [f64 chain][lane mode][path code] x
+    // variant = counters x cylinder/triangle code x hierarchy/gate code x area-light code
     const int variant = (stats ? 8 : 0) | (s->exotic ? 4 : 0) | (s->tree ? 2 : 0) | (s->area ? 1 : 0);
-// (timing experiments on ONE family, scripts/exp_build.sh: -DRT_EXP_ONLY_TREE compiles the plain hierarchy kernels only)
-#ifdef RT_EXP_ONLY_TREE
-#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, true, false, X, L, true>
-#elif defined(RT_EXP_ONLY_FLAT_AREA)  // (the headline's kernels only)
-#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, false, true, X, false, P>
-#elif defined(RT_EXP_ONLY_TREE_AREA)  // (cover_image_area's kernels only)
-#define RT_K(S, E, T, A, X, L, P) render_kernel<S, false, true, true, X, false, true>
-#else
-#define RT_K(S, E, T, A, X, L, P) render_kernel<S, E, T, A, X, (T) && (L), (P) || ((T) && (L))>
-#endif
-#define RT_KERNELS(X, L, P)                                                                                            \
-    {RT_K(false, false, false, false, X, L, P), RT_K(false, false, false, true, X, L, P),                              \
-     RT_K(false, false, true, false, X, L, P),  RT_K(false, false, true, true, X, L, P),                               \
-     RT_K(false, true, false, false, X, L, P),  RT_K(false, true, false, true, X, L, P),                               \
-     RT_K(false, true, true, false, X, L, P),   RT_K(false, true, true, true, X, L, P),                                \
-     RT_K(true, false, false, false, X, L, P),  RT_K(true, false, false, true, X, L, P),                               \
-     RT_K(true, false, true, false, X, L, P),   RT_K(true, false, true, true, X, L, P),                                \
-     RT_K(true, true, false, false, X, L, P),   RT_K(true, true, false, true, X, L, P),                                \
-     RT_K(true, true, true, false, X, L, P),    RT_K(true, true, true, true, X, L, P)}
-    // [f64 chain][lane mode][spawning materials][variant]; lane mode only exists for the hierarchy variants and only
-    // with the path code (the other entries repeat their neighbours)
-    void (*const kernels[2][2][2][16])(const KParams) = {
-        {{RT_KERNELS(false, false, false), RT_KERNELS(false, false, true)}, {RT_KERNELS(false, true, false), RT_KERNELS(false, true, true)}},
-        {{RT_KERNELS(true, false, false), RT_KERNELS(true, false, true)}, {RT_KERNELS(true, true, false), RT_KERNELS(true, true, true)}}};
-#undef RT_KERNELS
-#undef RT_K
-    hipLaunchKernelGGL(kernels[exact ? 1 : 0][(s->lane && s->tree) ? 1 : 0][s->spawn ? 1 : 0][variant], dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
+    const bool lane = s->lane && s->tree;
+    const int group = (exact ? 4 : 0) | (lane ? 2 : 0) | ((s->spawn || lane) ? 1 : 0);  // lane mode always holds the path code
+    KernelFn kernel = nullptr;
+    switch (group) {
+        case 0: kernel = kernel_group_0(variant); break;
+        case 1: kernel = kernel_group_1(variant); break;
+        case 3: kernel = kernel_group_3(variant); break;
+        case 4: kernel = kernel_group_4(variant); break;
+        case 5: kernel = kernel_group_5(variant); break;
+        case 7: kernel = kernel_group_7(variant); break;
+        default: break;
+    }
+    if (!kernel) return fail(RT_ERR_UNSUPPORTED, "no render kernel for this scene (library built with a reduced kernel set)");
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
