@@ -1,4 +1,4 @@
-//! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 2).  What `bindgen` would emit, written
+//! Raw declarations of `include/rt_amd.h` (RT_ABI_VERSION 3).  What `bindgen` would emit, written
 //! by hand because the header is small and stable.  UNVERIFIED: no Rust toolchain exists in the
 //! environment this was written in; the C++ mirror of the same calls is what is compiled and tested.
 //! `tests/test_rust_binding.py` parses this file and the header and compares every function (argument
@@ -6,7 +6,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 2;
+pub const RT_ABI_VERSION: u32 = 3;
 pub const RT_ITEM_NODE: u32 = 0x8000_0000;
 pub const RT_OK: c_int = 0;
 pub const RT_ERR_BAD_ARGUMENT: c_int = -1;
@@ -166,6 +166,7 @@ extern "C" {
 
 pub const RT_FLAG_GLOBAL_ROWS: u32 = 1;
 pub const RT_FLAG_F32_ONLY: u32 = 2;
+pub const RT_FLAG_DEPTH_ZERO: u32 = 4;
 pub const RT_VARIANT_AREA: u32 = 1;
 pub const RT_VARIANT_TREE: u32 = 2;
 pub const RT_VARIANT_EXOTIC: u32 = 4;

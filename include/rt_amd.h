@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -132,9 +132,16 @@ typedef struct rt_camera_desc {
  * this call renders bands tile_first, tile_first + tile_stride, ... and packs them one after
  * another into the output (band k of this call starts at output row k * tile_rows).  The defaults
  * (tile_rows = 0) render the whole image.  The jitter hash is keyed on the GLOBAL pixel index, so
- * the image does not depend on the partition. */
+ * the image does not depend on the partition: BIT FOR BIT when tile_rows is a multiple of 8 (the
+ * kernels work on 8x8 pixel tiles of the packed rows, so every tile then holds the same pixels
+ * as in the whole frame; raytracer_amd/partition.py uses 8).  With other band heights the tiles
+ * hold other pixels, and two sums follow the tile's composition — a pixel's path nodes added up
+ * in the order its wave finished them (ray stealing, lane-mode kernels) and the Phong sums shared
+ * out over the idle lanes of a sparse wave — so a pixel can differ in its last bits (<= 1e-6
+ * relative; tests/test_gpu_parity.py::test_unaligned_bands_differ_in_the_last_bits_only). */
 typedef struct rt_options {
-    uint32_t max_depth;            /* world.rs:11 RECURSION_DEPTH; 0 in a zeroed struct means 5      */
+    uint32_t max_depth;            /* world.rs:11 RECURSION_DEPTH; 0 in a zeroed struct means 5
+                                      (RT_FLAG_DEPTH_ZERO asks for depth 0 itself)                   */
     uint32_t jitter_mode;          /* RT_JITTER_*                                                    */
     uint32_t seed;
     uint32_t tile_rows, tile_first, tile_stride;
@@ -151,6 +158,10 @@ typedef struct rt_options {
 /* Render with the FP32 path only even though the scene and the camera carry f64 tables (timing the
  * f64 chain's share, parity experiments). */
 #define RT_FLAG_F32_ONLY 2u
+/* ABI 3.  World::color_at(ray, 0) (world.rs:24): the surface term of the first hit only — reflected_color and
+ * refracted_color return BLACK at depth 0 (world.rs:97,119).  A flag because max_depth = 0 in a zeroed struct
+ * keeps meaning RECURSION_DEPTH = 5; with this flag max_depth must be 0. */
+#define RT_FLAG_DEPTH_ZERO 4u
 
 /* Ray and work counters of one render.  primary/reflection/refraction rays are traced one by one and
  * counted once each (the reference re-traces the recursion once per light, world.rs:59-60; that
@@ -205,8 +216,9 @@ int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint
  *                     `stream` (a hipStream_t passed as void*, NULL = the default stream) and the
  *                     call returns without waiting.  Allocates nothing, with one exception: a scene
  *                     with transparent materials keeps a tile-cost table of 20 bytes per 8x8 tile
- *                     (every wave leaves the time its tile took; the next frame with the same tiling
- *                     starts its expensive tiles first — same image, shorter tail).  The first call
+ *                     (every wave leaves a cost figure of its tile: ten per round of its path loop
+ *                     plus one per visibility pass; the next frame with the same tiling starts its
+ *                     expensive tiles first — same image, shorter tail).  The first call
  *                     with a frame of 8192 tiles or more that is larger than any before waits for the
  *                     stream, allocates that table and keeps it until rt_scene_destroy
  *                     (RT_AMD_NO_TILE_ORDER=1 in the environment: never).  Calls on one scene must be
@@ -223,8 +235,11 @@ int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_opti
                     float* rgb_out_host, rt_stats* stats_out);
 
 /* rt_render_stats for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
- * callers that may not call hipMalloc — code under HIP graph capture restrictions, tight serving
- * loops, harnesses that forbid allocation.  Same kernel, image and counters as rt_render_stats, but
+ * callers that may not call hipMalloc — tight serving loops, harnesses that forbid allocation, code
+ * that runs beside a graph capture on another stream.  The call itself is SYNCHRONOUS on `stream` (it
+ * records events, copies the counters to the host and waits), so it cannot run ON a capturing stream;
+ * host outputs land in pageable memory unless the caller passes pinned buffers.  Same kernel, image and
+ * counters as rt_render_stats, but
  *   - the image goes to DEVICE memory the caller passes (rows * hsize * 3 floats, as rt_render_device);
  *   - the kernel's scratch (counter block + per-tile ray map) lives in a static device array of the
  *     library: RT_NOALLOC_MAX_TILES * 4 + 256 bytes held on every GPU the library runs on until the

@@ -39,9 +39,12 @@ const char* oracle_last_error() { return g_error.c_str(); }
 // per-light duplicated recursion), shaded hits, light cells, pattern lookups, then primitive
 // tests by Shape kind {cube, cylinder, group(box), plane, smooth triangle, sphere, triangle}.
 // seconds_out: wall time of Camera::render only (scene construction excluded).
-int oracle_render_example(const char* name, int width, int height, int jitter_mode, uint32_t seed, int threads,
-                          int row_begin, int row_end, double* rgb, uint64_t* stats_out, double* seconds_out) {
+// depth: the `remaining` argument World::color_at starts with (world.rs:24); the reference's Camera::render passes
+// RECURSION_DEPTH = 5 (camera.rs:193, world.rs:11); negative = that default.
+int oracle_render_example_depth(const char* name, int width, int height, int jitter_mode, uint32_t seed, int threads,
+                                int row_begin, int row_end, double* rgb, uint64_t* stats_out, double* seconds_out, int depth) {
     try {
+        if (depth > 255) return fail("depth out of range");
         if (!name || !rgb || width <= 0 || height <= 0) return fail("bad argument");
         Scene scene;
         if (!examples::build(name, static_cast<size_t>(width), static_cast<size_t>(height), scene))
@@ -54,6 +57,7 @@ int oracle_render_example(const char* name, int width, int height, int jitter_mo
         opt.row_begin = static_cast<size_t>(row_begin);
         opt.row_end = static_cast<size_t>(row_end);
         opt.stats = stats_out ? &stats : nullptr;
+        if (depth >= 0) opt.depth = static_cast<uint8_t>(depth);
         auto t0 = std::chrono::steady_clock::now();
         Canvas img = scene.camera.render(scene.world, opt);
         auto t1 = std::chrono::steady_clock::now();
@@ -70,6 +74,11 @@ int oracle_render_example(const char* name, int width, int height, int jitter_mo
     } catch (const std::exception& e) {
         return fail(e.what());
     }
+}
+
+int oracle_render_example(const char* name, int width, int height, int jitter_mode, uint32_t seed, int threads,
+                          int row_begin, int row_end, double* rgb, uint64_t* stats_out, double* seconds_out) {
+    return oracle_render_example_depth(name, width, height, jitter_mode, seed, threads, row_begin, row_end, rgb, stats_out, seconds_out, -1);
 }
 
 // Colours of n individual pixels (xy = n pairs) of the scene at full resolution width x height.

@@ -1314,6 +1314,8 @@ struct RenderOptions {
     unsigned threads = 0;  // 0 => env RENDER_THREADS or 8 (camera.rs:16,167-170)
     size_t row_begin = 0, row_end = 0;  // row_end == 0 => all rows
     RayStats* stats = nullptr;
+    // the `remaining` argument of World::color_at (world.rs:24); Camera::render passes RECURSION_DEPTH (camera.rs:193)
+    uint8_t depth = RECURSION_DEPTH;
 };
 
 struct Camera {
@@ -1353,7 +1355,7 @@ struct Camera {
     Color color_for_pixel(const World& world, size_t x, size_t y, const RenderOptions& opt, TraceCtx& ctx) const {
         ctx.pixel_key = jitter_pixel_key(opt.seed, static_cast<uint32_t>(y * hsize + x));
         ctx.node = 0;
-        return world.color_at(ray_for_pixel(x, y), RECURSION_DEPTH, ctx, true);
+        return world.color_at(ray_for_pixel(x, y), opt.depth, ctx, true);
     }
     // camera.rs:163-208: one task per image row on a pool of RENDER_THREADS workers, each row is
     // buffered and written to the canvas under a mutex.  (The progress bar is not restated.)

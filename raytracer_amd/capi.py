@@ -269,8 +269,9 @@ def band_rows(vsize: int, tile_rows: int, tile_first: int = 0, tile_stride: int 
 
 RT_FLAG_GLOBAL_ROWS = 1
 RT_FLAG_F32_ONLY = 2
+RT_FLAG_DEPTH_ZERO = 4
 RT_NOALLOC_MAX_TILES = 131072
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 
 
 class SharedFrame:

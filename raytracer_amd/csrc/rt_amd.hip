@@ -69,11 +69,11 @@ int plan_render(const rt_camera_desc* cam, const rt_options* opt, RenderPlan& rp
     if (static_cast<uint64_t>(cam->hsize) * cam->vsize > 0x7FFFFFFFull) return fail(RT_ERR_CAPACITY, "image too large");
     rt_options o{};
     if (opt) o = *opt;
-    if (o.flags & ~(RT_FLAG_GLOBAL_ROWS | RT_FLAG_F32_ONLY)) return fail(RT_ERR_BAD_ARGUMENT, "options.flags holds an unknown bit");
+    if (o.flags & ~(RT_FLAG_GLOBAL_ROWS | RT_FLAG_F32_ONLY | RT_FLAG_DEPTH_ZERO)) return fail(RT_ERR_BAD_ARGUMENT, "options.flags holds an unknown bit");
     rp.global_rows = (o.flags & RT_FLAG_GLOBAL_ROWS) != 0;
     rp.f32_only = (o.flags & RT_FLAG_F32_ONLY) != 0;
     if (o.jitter_mode > RT_JITTER_COUNTER) return fail(RT_ERR_UNSUPPORTED, "unknown jitter mode");
-    rp.max_depth = o.max_depth ? o.max_depth : 5u;
+    if (!options_max_depth(&o, rp.max_depth)) return fail(RT_ERR_BAD_ARGUMENT, "RT_FLAG_DEPTH_ZERO goes with max_depth = 0");
     if (rp.max_depth > RT_MAX_DEPTH) return fail(RT_ERR_CAPACITY, "max_depth exceeds RT_MAX_DEPTH");
     if (o.tile_rows == 0) {
         rp.tile_rows = cam->vsize, rp.tile_first = 0, rp.tile_stride = 1, rp.out_rows = cam->vsize;

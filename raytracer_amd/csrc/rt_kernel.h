@@ -114,7 +114,7 @@ struct KParams {
     unsigned long long* counters;  // STATS variant only: kCounters x u64
     uint32_t* tile_rays;           // STATS variant only, may be null: rays cast per 8x8 tile, raster order of this call's rows
     const uint32_t* tile_order;    // may be null: the tile slot each wave renders (expensive tiles first), else the wave's own index
-    uint32_t* tile_cost;           // may be null: per tile (raster index), the clock ticks its wave ran for
+    uint32_t* tile_cost;           // may be null: per tile (raster index), 10 x rounds of its path loop + visibility passes (the tile order of the next frame)
     uint32_t max_depth, jitter_mode, seed;
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;

@@ -634,6 +634,19 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     return RT_OK;
 }
 
+// rt_options.max_depth as the kernels take it (world.rs:11,24): 0 in a zeroed struct is RECURSION_DEPTH = 5,
+// RT_FLAG_DEPTH_ZERO is depth 0 itself.  false: the flag together with a nonzero max_depth.
+inline bool options_max_depth(const rt_options* o, uint32_t& depth) {
+    depth = 5u;
+    if (!o) return true;
+    if (o->flags & RT_FLAG_DEPTH_ZERO) {
+        depth = 0u;
+        return o->max_depth == 0u;
+    }
+    if (o->max_depth) depth = o->max_depth;
+    return true;
+}
+
 inline XCamera pack_camera64(const rt_camera_desc& c) {
     XCamera x{};
     x.pixel_size = c.pixel_size64, x.half_width = c.half_width64, x.half_height = c.half_height64;

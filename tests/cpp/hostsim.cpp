@@ -506,7 +506,7 @@ extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* c
     s.cam = pack_camera(*camera);
     s.cam64 = pack_camera64(*camera);
     s.exact = s.ps.has_f64 && camera->has_f64 != 0 && !(options && (options->flags & RT_FLAG_F32_ONLY));
-    s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
+    options_max_depth(options, s.max_depth);
     s.jitter_mode = options ? options->jitter_mode : 0u;
     s.seed = options ? options->seed : 0u;
     const uint32_t W = camera->hsize, H = camera->vsize;
@@ -550,7 +550,7 @@ extern "C" int hostsim_trace_pixels(const rt_scene_desc* desc, const rt_camera_d
     s.cam = pack_camera(*camera);
     s.cam64 = pack_camera64(*camera);
     s.exact = s.ps.has_f64 && camera->has_f64 != 0 && !(options && (options->flags & RT_FLAG_F32_ONLY));
-    s.max_depth = (options && options->max_depth) ? options->max_depth : 5u;
+    options_max_depth(options, s.max_depth);
     s.jitter_mode = options ? options->jitter_mode : 0u;
     s.seed = options ? options->seed : 0u;
     std::vector<double> tr;

@@ -36,6 +36,7 @@ def oracle():
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_render_example.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_render_example_depth.argtypes = L.oracle_render_example.argtypes + [C.c_int]
         L.oracle_probe_pixels.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_quantize_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.oracle_quantize_u8.restype = None
@@ -52,15 +53,16 @@ ORACLE_STAT_NAMES = ["primary", "reflect", "refract", "shadow", "shaded_hits", "
 
 
 def oracle_render(name: str, width: int, height: int, jitter: int = JITTER_CENTER, seed: int = 0, threads: int = 0,
-                  rows: Optional[Tuple[int, int]] = None, want_stats: bool = False):
-    """f64 oracle render.  Returns (rgb[h, w, 3] float64, stats dict or None, seconds)."""
+                  rows: Optional[Tuple[int, int]] = None, want_stats: bool = False, depth: int = -1):
+    """f64 oracle render.  Returns (rgb[h, w, 3] float64, stats dict or None, seconds).
+    depth: what World::color_at starts with (world.rs:24); -1 = the reference's RECURSION_DEPTH = 5."""
     L = oracle()
     rgb = np.zeros((height, width, 3), dtype=np.float64)
     stats = np.zeros(14, dtype=np.uint64)
     sec = C.c_double()
     r0, r1 = rows if rows else (0, 0)
-    rc = L.oracle_render_example(name.encode(), width, height, jitter, seed, threads, r0, r1, rgb.ctypes.data,
-                                 stats.ctypes.data if want_stats else None, C.byref(sec))
+    rc = L.oracle_render_example_depth(name.encode(), width, height, jitter, seed, threads, r0, r1, rgb.ctypes.data,
+                                       stats.ctypes.data if want_stats else None, C.byref(sec), depth)
     if rc != 0:
         raise RuntimeError(L.oracle_last_error().decode())
     sd = dict(zip(ORACLE_STAT_NAMES, (int(v) for v in stats))) if want_stats else None
@@ -151,7 +153,7 @@ def triangle_soup_desc(n: int, keep: list):
     ref, nxt = np.arange(n + 1, dtype=np.uint32), np.arange(1, n + 2, dtype=np.uint32)
     from raytracer_amd import RtSceneDesc
     d = RtSceneDesc()
-    d.abi_version = 2
+    d.abi_version = 3
     d.n_prims, d.prim_type, d.prim_inv = n + 1, types.ctypes.data, inv.ctypes.data
     d.prim_material, d.prim_param = mats.ctypes.data, params.ctypes.data
     d.n_items, d.item_ref, d.item_next = n + 1, ref.ctypes.data, nxt.ctypes.data

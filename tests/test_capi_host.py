@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     L = lib()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.rt_abi_version() == capi.RT_ABI_VERSION == 2
+    assert L.rt_abi_version() == capi.RT_ABI_VERSION == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -79,8 +79,13 @@ def test_option_and_camera_validation():
     o.tile_rows, o.tile_first, o.tile_stride = 8, 2, 2
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     o = RtOptions()
-    o.flags = 4  # an unknown bit (1 = RT_FLAG_GLOBAL_ROWS, 2 = RT_FLAG_F32_ONLY)
+    o.flags = 8  # an unknown bit (1 = RT_FLAG_GLOBAL_ROWS, 2 = RT_FLAG_F32_ONLY, 4 = RT_FLAG_DEPTH_ZERO)
     assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
+    o = RtOptions()
+    o.flags, o.max_depth = 4, 3  # depth 0 is asked for by the flag alone
+    assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == RT_ERR_BAD_ARGUMENT
+    o.max_depth = 0
+    assert L.rt_output_rows(C.byref(cam), C.byref(o), C.byref(rows)) == 0
     assert L.rt_output_rows(None, None, C.byref(rows)) == RT_ERR_BAD_ARGUMENT
     assert L.rt_render(None, C.byref(cam), None, None, None) == RT_ERR_BAD_ARGUMENT
 

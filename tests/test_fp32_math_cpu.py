@@ -90,21 +90,36 @@ def test_reference_end_to_end_pixel():
     assert np.abs(sim[5, 5] - np.array([0.38066, 0.47583, 0.2855])).max() <= 1e-5  # camera.rs:353-360
 
 
-@pytest.mark.parametrize("depth", [1, 2, 8])
+@pytest.mark.parametrize("depth", [0, 1, 2, 8])
 def test_depth_limit(depth):
-    # the recursion limit is a parameter of the kernel (world.rs:11 fixes it to 5); the oracle only
-    # knows 5, so other depths are checked for monotone convergence towards it
+    """The recursion limit is the `remaining` argument of World::color_at (world.rs:24; Camera::render passes 5,
+    camera.rs:193).  Depth 0 is the surface term only (world.rs:97,119) and needs RT_FLAG_DEPTH_ZERO, because
+    max_depth = 0 in a zeroed rt_options means 5."""
     ex = ExampleScene("cover_image", 48, 27)
-    imgs = {}
-    for d in (depth, 5):
-        o = RtOptions()
-        o.max_depth = d
-        imgs[d] = H.hostsim_render(ex, o)
-    ref, _, _ = H.oracle_render("cover_image", 48, 27, threads=4)
-    e_d = np.abs(imgs[depth] - ref).mean()
-    e_5 = np.abs(imgs[5] - ref).mean()
-    assert e_5 <= 1e-6
-    assert (e_d > e_5) if depth < 5 else (e_d < 1e-3)
+    o = RtOptions()
+    o.max_depth, o.flags = depth, (4 if depth == 0 else 0)
+    img = H.hostsim_render(ex, o)
+    ref, _, _ = H.oracle_render("cover_image", 48, 27, threads=4, depth=depth)
+    assert H.compare(img, ref, TOL)["bad_pixels"] <= 1
+    ref5, _, _ = H.oracle_render("cover_image", 48, 27, threads=4)
+    if depth < 5:
+        assert np.abs(ref - ref5).mean() > 1e-4  # every object of the scene is reflective: the depth matters
+    o = RtOptions()  # a zeroed struct renders the reference's depth
+    assert np.array_equal(H.hostsim_render(ex, o), H.hostsim_render(ex, None))
+    assert H.compare(H.hostsim_render(ex, o), ref5, TOL)["bad_pixels"] <= 1
+
+
+def test_depth_zero_known_answers_of_the_reference():
+    """world.rs:575-600 / 660-690: reflected_color and refracted_color at depth 0 are BLACK, so color_at(ray, 0) is
+    the surface term alone.  test_world's inner sphere has ambient 1 (world.rs:163-170): from inside it every pixel of
+    a depth-0 render is that material's ambient colour; cover_image at depth 0 equals the oracle's depth 0."""
+    ex = ExampleScene("glass_sphere_checkered_floor_aerial_view", 48, 27)
+    o = RtOptions()
+    o.flags = 4
+    img = H.hostsim_render(ex, o)
+    ref, st, _ = H.oracle_render("glass_sphere_checkered_floor_aerial_view", 48, 27, threads=4, depth=0, want_stats=True)
+    assert st["reflect"] == 0 and st["refract"] == 0  # no recursive ray at all
+    assert H.compare(img, ref, TOL)["bad_pixels"] <= 1
 
 
 def test_full_resolution_probes_cover_image():

@@ -146,6 +146,33 @@ def test_band_partition_is_invisible_at_full_size(name, world):
     assert np.array_equal(bufs[partition.gather_permutation(h, world)], full)
 
 
+def test_unaligned_bands_differ_in_the_last_bits_only():
+    """rt_amd.h's contract for tile_rows that is NOT a multiple of 8: the packed rows then form other 8x8 tiles than
+    the whole frame's, and the two sums that follow a tile's composition (ray stealing's per-pixel sum in the
+    lane-mode kernels, the shared Phong sums of sparse waves) may round differently: last bits only.  Aligned bands
+    of the same scenes stay bit-identical."""
+    for name, w, h in (("multiple_glass_and_metallic_spheres", 480, 270), ("glass_sphere_checkered_floor_aerial_view", 320, 180)):
+        ex = ExampleScene(name, w, h)
+        sc = Scene(ex.scene_desc, 0)
+        base = RtOptions()
+        base.jitter_mode, base.seed = 1, 11
+        full, _ = sc.render(ex.camera_desc, base)
+        for tile_rows, exact in ((16, True), (5, False), (13, False)):
+            got = np.zeros_like(full)
+            for first in range(3):
+                o = RtOptions()
+                o.jitter_mode, o.seed = 1, 11
+                o.tile_rows, o.tile_first, o.tile_stride = tile_rows, first, 3
+                part, _ = sc.render(ex.camera_desc, o)
+                got[band_rows(h, tile_rows, first, 3)] = part
+            if exact:
+                assert np.array_equal(got, full), (name, tile_rows)
+            else:
+                err = np.abs(got - full) / np.maximum(1.0, np.abs(full))
+                assert float(err.max()) <= 1e-6, (name, tile_rows, float(err.max()))
+        sc.close()
+
+
 def test_render_is_deterministic_and_device_entry_matches_host_entry():
     import torch
 
@@ -158,6 +185,7 @@ def test_render_is_deterministic_and_device_entry_matches_host_entry():
     assert np.array_equal(a, b) and st.kernel_ms > 0
     out = torch.zeros((180, 320, 3), dtype=torch.float32, device="cuda:0")
     s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())  # the zero fill runs on torch's stream: order it before the render on `s`
     with torch.cuda.stream(s):
         sc.render_device(ex.camera_desc, out.data_ptr(), opt, s.cuda_stream)  # caller's stream, no allocation
     s.synchronize()
@@ -214,14 +242,21 @@ def test_edge_cases():
     sc.close()
     img, _ = _render("test_world", 1, 1)
     assert img.shape == (1, 1, 3) and img[0, 0, 1] > 0.3  # the single pixel looks at the sphere
-    # depth limit: 0 => only the surface term; 8 = RT_MAX_DEPTH; 9 rejected
+    # depth limit: RT_FLAG_DEPTH_ZERO => only the surface term (world.rs:97,119); 8 = RT_MAX_DEPTH; 9 rejected
     ex = ExampleScene("cover_image", 64, 36)
     sc = Scene(ex.scene_desc, 0)
     imgs = {}
-    for dep in (1, 5, 8):
+    for dep in (0, 1, 3, 5, 8):
         o = RtOptions()
-        o.max_depth = dep
-        imgs[dep], _ = sc.render(ex.camera_desc, o)
+        o.max_depth, o.flags = dep, (4 if dep == 0 else 0)
+        imgs[dep], st = sc.render(ex.camera_desc, o, stats=True)
+        ref, _, _ = H.oracle_render("cover_image", 64, 36, threads=8, depth=dep)  # color_at(ray, dep), world.rs:24
+        assert H.compare(imgs[dep], ref)["bad_pixels"] <= 1, dep
+        if dep == 0:  # reflected_color / refracted_color at depth 0 are BLACK: no recursive ray is cast
+            assert st.reflection_rays == 0 and st.refraction_rays == 0 and st.primary_rays == 64 * 36
+    assert float(np.abs(imgs[0] - imgs[1]).mean()) > 1e-3
+    img_default, _ = sc.render(ex.camera_desc, RtOptions())  # a zeroed struct keeps meaning RECURSION_DEPTH = 5
+    assert np.array_equal(img_default, imgs[5])
     d15, d85 = float(np.abs(imgs[1] - imgs[5]).mean()), float(np.abs(imgs[8] - imgs[5]).mean())
     assert d15 > 1e-3 and d85 < 0.2 * d15, (d15, d85)  # deeper paths carry geometrically less weight
     o = RtOptions()

@@ -141,7 +141,7 @@ def test_every_constant_and_enum_value_matches():
 def test_header_constants_agree_with_the_python_binding_too():
     from raytracer_amd import capi
     c_consts, _, _ = parse_header()
-    for k in ("RT_ABI_VERSION", "RT_FLAG_GLOBAL_ROWS", "RT_FLAG_F32_ONLY", "RT_NOALLOC_MAX_TILES"):
+    for k in ("RT_ABI_VERSION", "RT_FLAG_GLOBAL_ROWS", "RT_FLAG_F32_ONLY", "RT_FLAG_DEPTH_ZERO", "RT_NOALLOC_MAX_TILES"):
         assert getattr(capi, k) == c_consts[k], k
 
 

@@ -131,7 +131,7 @@ def random_scene(rng, n_objects, keep):
               l_u, l_v, l_us, l_vs, l_col, item_ref, item_next]
     keep += arrays
     d = RtSceneDesc()
-    d.abi_version = 2
+    d.abi_version = 3
     d.n_prims, d.prim_type, d.prim_inv = n, prim_type.ctypes.data, prim_inv.ctypes.data
     d.prim_material, d.prim_param = prim_mat.ctypes.data, prim_param.ctypes.data
     d.n_nodes, d.node_min, d.node_max = 0, None, None

@@ -24,6 +24,7 @@ def _both(name, w, h, opt):
     ref_img, ref_st = sc.render(ex.camera_desc, opt, stats=True)  # rt_render_stats
     out = torch.full((h, w, 3), -7.0, dtype=torch.float32, device="cuda:0")
     s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())  # the fill runs on torch's stream: order it before the render on `s`
     st, tiles = sc.render_stats_noalloc(ex.camera_desc, out.data_ptr(), opt, s.cuda_stream, want_tiles=True)
     got = out.cpu().numpy()
     sc.close()
@@ -57,6 +58,7 @@ def test_no_alloc_entry_point_rejects_what_its_scratch_cannot_hold():
     o.tile_rows, o.tile_first, o.tile_stride = 8, 1, 4
     rows = sc.output_rows(ex.camera_desc, o)
     out = torch.zeros((rows, 4096, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()  # (the render below goes to the null stream of HIP, not to torch's current stream)
     st2, _ = sc.render_stats_noalloc(ex.camera_desc, out.data_ptr(), o, 0)
     ref, ref_st = sc.render(ex.camera_desc, o, stats=True)
     assert np.array_equal(out.cpu().numpy(), ref) and st2.primary_rays == ref_st.primary_rays == rows * 4096
