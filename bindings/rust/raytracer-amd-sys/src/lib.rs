@@ -66,6 +66,8 @@ pub struct rt_scene_desc {
     pub prim_param64: *const f64,
     pub mat_ior64: *const f64,
     pub pat_inv64: *const f64,
+    // optional: position (area: corner), uvec, vvec of every light in f64, nine a light (null: the f32 values)
+    pub light_geom64: *const f64,
 }
 
 #[repr(C)]

@@ -66,6 +66,7 @@ pub(crate) struct FlatScene {
     prim_param64: Vec<f64>,
     mat_ior64: Vec<f64>,
     pat_inv64: Vec<f64>,
+    light_geom64: Vec<f64>, // position (area: corner), uvec, vvec: nine a light
 }
 
 /// First three rows of an affine 4x4, row-major, f64 -> f32 (rounded once).
@@ -212,6 +213,7 @@ impl FlatScene {
                 self.light_pos.extend_from_slice(&[p.position.0.x as f32, p.position.0.y as f32, p.position.0.z as f32]);
                 self.light_uvec.extend_from_slice(&[0.0; 3]);
                 self.light_vvec.extend_from_slice(&[0.0; 3]);
+                self.light_geom64.extend_from_slice(&[p.position.0.x, p.position.0.y, p.position.0.z, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]);
                 self.light_usteps.push(1);
                 self.light_vsteps.push(1);
                 push_color(&mut self.light_color, p.intensity);
@@ -221,6 +223,9 @@ impl FlatScene {
                 self.light_pos.extend_from_slice(&[a.corner.0.x as f32, a.corner.0.y as f32, a.corner.0.z as f32]);
                 self.light_uvec.extend_from_slice(&[a.uvec.0.x as f32, a.uvec.0.y as f32, a.uvec.0.z as f32]);
                 self.light_vvec.extend_from_slice(&[a.vvec.0.x as f32, a.vvec.0.y as f32, a.vvec.0.z as f32]);
+                self.light_geom64.extend_from_slice(&[
+                    a.corner.0.x, a.corner.0.y, a.corner.0.z, a.uvec.0.x, a.uvec.0.y, a.uvec.0.z, a.vvec.0.x, a.vvec.0.y, a.vvec.0.z,
+                ]);
                 self.light_usteps.push(a.usteps as u32);
                 self.light_vsteps.push(a.vsteps as u32);
                 push_color(&mut self.light_color, a.intensity);
@@ -263,6 +268,7 @@ impl FlatScene {
             prim_param64: self.prim_param64.as_ptr(),
             mat_ior64: self.mat_ior64.as_ptr(),
             pat_inv64: self.pat_inv64.as_ptr(),
+            light_geom64: self.light_geom64.as_ptr(),
         }
     }
 }

@@ -444,6 +444,7 @@ struct FlatScene {
     std::vector<float> light_pos, light_uvec, light_vvec, light_color;
     std::vector<uint32_t> prim_material, item_ref, item_next, mat_pattern, light_usteps, light_vsteps;
     std::vector<double> prim_inv64, prim_param64, mat_ior64, pat_inv64;  // the f64 values themselves (rt_exact.h)
+    std::vector<double> light_geom64;                                    // position (area: corner), uvec, vvec: nine a light
 
     rt_scene_desc desc() const {
         rt_scene_desc d{};
@@ -466,6 +467,7 @@ struct FlatScene {
         d.light_color = light_color.data();
         d.prim_inv64 = prim_inv64.data(), d.prim_param64 = prim_param64.data();
         d.mat_ior64 = mat_ior64.data(), d.pat_inv64 = pat_inv64.data();
+        d.light_geom64 = light_geom64.data();
         return d;
     }
 };
@@ -588,6 +590,8 @@ inline FlatScene flatten(const World& world) {
         detail::push3(f.out.light_pos, l.position.x, l.position.y, l.position.z);
         detail::push3(f.out.light_uvec, l.uvec.x, l.uvec.y, l.uvec.z);
         detail::push3(f.out.light_vvec, l.vvec.x, l.vvec.y, l.vvec.z);
+        for (double v : {l.position.x, l.position.y, l.position.z, l.uvec.x, l.uvec.y, l.uvec.z, l.vvec.x, l.vvec.y, l.vvec.z})
+            f.out.light_geom64.push_back(v);
         f.out.light_usteps.push_back(static_cast<uint32_t>(l.usteps));
         f.out.light_vsteps.push_back(static_cast<uint32_t>(l.vsteps));
         detail::push3(f.out.light_color, l.intensity.red, l.intensity.green, l.intensity.blue);

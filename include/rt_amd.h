@@ -116,6 +116,11 @@ typedef struct rt_scene_desc {
     const double* prim_param64;    /* [n_prims][24]  same layout as prim_param                       */
     const double* mat_ior64;       /* [n_materials]  index_of_refraction                             */
     const double* pat_inv64;       /* [n_patterns][12]                                               */
+    /* Optional (ABI 3), used with the four tables above: the lights' geometry in the caller's f64 — position
+     * (area: corner), uvec, vvec, nine doubles a light (light.rs:42-48,81-89).  With it the shadow rays FP32
+     * cannot settle (a ray grazing an occluder, a point within 1e-4 of another surface) are decided from the
+     * f64 over point towards the f64 light position (world.rs:73-92).  NULL: the f32 values are widened. */
+    const double* light_geom64;    /* [n_lights][9]                                                   */
 } rt_scene_desc;
 
 /* Camera, camera.rs:64-73 after Camera::try_from (camera.rs:95-136). */

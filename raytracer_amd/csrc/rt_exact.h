@@ -319,6 +319,7 @@ struct XHit {
     D3 point, normal, eye, reflectv, over, under;
     D3 qobj;    // the hit point in object space; the coordinate a face / cap / plane fixes is set exactly
     int qround;  // what is left for FP32 (xsnap_q): 1 = scale onto the unit sphere, 2 = x, z onto the unit circle
+    bool qedge;  // a cube's point within 1e-5 of an edge that got the NEIGHBOURING face's normal (below): not snapped
     bool inside;
 };
 template <bool EXOTIC = true>
@@ -327,7 +328,7 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
     h.point = ro + rd * t;  // ray.rs:13-15
     h.eye = xneg(rd);
     const D3 p = xpoint(inv, h.point);
-    h.qobj = p, h.qround = 0;
+    h.qobj = p, h.qround = 0, h.qedge = false;
     D3 nobj = d3(0.0, 1.0, 0.0);
     switch (type) {
         case PRIM_SPHERE:  // sphere.rs:74-76
@@ -342,9 +343,26 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
             const double ax = fabs(p.x), ay = fabs(p.y), az = fabs(p.z);
             double mc = (ax > ay) ? ax : ay;  // max_by with the exact comparison: the largest value
             mc = (mc > az) ? mc : az;
-            if (xapprox(mc, ax)) nobj = d3(p.x, 0.0, 0.0), h.qobj.x = p.x < 0.0 ? -1.0 : 1.0;
-            else if (xapprox(mc, ay)) nobj = d3(0.0, p.y, 0.0), h.qobj.y = p.y < 0.0 ? -1.0 : 1.0;
-            else nobj = d3(0.0, 0.0, p.z), h.qobj.z = p.z < 0.0 ? -1.0 : 1.0;
+            // The coordinate of the face is set exactly — if the point IS on that face.  Within 1e-5 of an edge the
+            // approximate comparison gives the normal of the first axis in x, y, z order, which may belong to the
+            // NEIGHBOURING face (cover_image, pixel (1504, 406): a point on the front face, 9e-6 under the top edge, gets
+            // the top face's normal); the over point then lies inside the cube and the rays that leave it meet that
+            // face from within at t ~ 1e-5.  Such a point keeps its own coordinates.
+            // Such a point keeps its own coordinates, and whether the rays leaving it (shadow rays first of all) meet
+            // the cube again is the reference's own rounding noise — pixel (2471, 1404): the over point lies 1.8e-15
+            // inside the face it stands on, so every shadow ray "leaves the cube" at t = 1e-15 > 0 and is shadowed:
+            // qedge tells the shadow walks to ask f64 about the primitive itself (rt_kernel.h "unsure shadow rays").
+            constexpr double kOnFace = 1e-9;
+            if (xapprox(mc, ax)) {
+                nobj = d3(p.x, 0.0, 0.0), h.qedge = !(fabs(ax - 1.0) <= kOnFace);
+                if (!h.qedge) h.qobj.x = p.x < 0.0 ? -1.0 : 1.0;
+            } else if (xapprox(mc, ay)) {
+                nobj = d3(0.0, p.y, 0.0), h.qedge = !(fabs(ay - 1.0) <= kOnFace);
+                if (!h.qedge) h.qobj.y = p.y < 0.0 ? -1.0 : 1.0;
+            } else {
+                nobj = d3(0.0, 0.0, p.z), h.qedge = !(fabs(az - 1.0) <= kOnFace);
+                if (!h.qedge) h.qobj.z = p.z < 0.0 ? -1.0 : 1.0;
+            }
             break;
         }
         case PRIM_CYLINDER: {  // cylinder.rs:172-184
@@ -417,6 +435,38 @@ RT_HD bool xrefract(const XHit& h, double n1, double n2, D3& dir) {
     const double cos_t = sqrt(1.0 - sin2_t);
     dir = h.normal * (n_ratio * cos_i - cos_t) - h.eye * n_ratio;
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shadow rays FP32 cannot settle (rt_math.h occludes_prim_soft): World::is_shadowed (world.rs:73-92) against ONE
+// primitive, in f64 from the f64 over point to the f64 light position.  hit = the first t > 0 of the (sorted) list,
+// shadowed iff hit.t < distance: for one question "is there an intersection with 0 < t < distance".
+struct XLight {  // light.rs:42-48,81-89 in f64: point: position; area: corner, uvec, vvec
+    double pos[3], uvec[3], vvec[3];
+};
+// light.rs:211-216; the draws are bytes / 255 (light.rs:149-152), 0.5 in the deterministic mode
+RT_HD D3 xpoint_on_light(const XLight& l, uint32_t u, uint32_t v, double ju, double jv) {
+    const D3 c = d3(l.pos[0], l.pos[1], l.pos[2]), uv = d3(l.uvec[0], l.uvec[1], l.uvec[2]), vv = d3(l.vvec[0], l.vvec[1], l.vvec[2]);
+    return c + uv * (static_cast<double>(u) + ju) + vv * (static_cast<double>(v) + jv);
+}
+template <bool EXOTIC = true>
+RT_HD bool xoccludes(uint32_t type, const double* inv, const double* e, D3 point, D3 light_position) {
+    const D3 point_to_light = light_position - point;
+    const double distance = xmagnitude(point_to_light);
+    D3 dir = d3(0.0, 0.0, 0.0);
+    if (!xnormalize(point_to_light, dir)) return false;
+    const XHits h = xintersect<EXOTIC>(type, inv, e, point, dir);
+    bool occ = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) occ |= (h.t[k] > 0.0) & (h.t[k] < distance);  // (absent = +inf)
+    return occ;
+}
+// The jitter draws of rt_math.h counter_jitter as the reference forms them: byte as f64 / 255.0
+RT_HD void xcounter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, double& ju, double& jv) {
+    uint32_t k = (node << 24) | (light << 16) | cell;
+    uint32_t h = fmix32(pixel_key + k * 0x85EBCA77u + (node >> 8) * 0x27D4EB2Fu);
+    ju = static_cast<double>(h >> 24) / 255.0;
+    jv = static_cast<double>((h >> 16) & 0xFFu) / 255.0;
 }
 
 }  // namespace rtk

@@ -102,6 +102,7 @@ struct KScene {
     const XExtra* xextras;
     const double* xior;
     const XPattern* xpats;
+    const XLight* xlights;  // per light (always there: the caller's f64 geometry, or the f32 values widened)
     uint32_t n_items, n_lights;
     uint32_t has_gates, has_bvh;
     uint32_t any_spawn;  // some material is reflective or transparent (no path has a second node otherwise)
@@ -308,21 +309,73 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
     }
 }
 
+// The f64 answer for ONE primitive and ONE shadow ray (rt_exact.h xoccludes: world.rs:73-92 with the reference's own
+// arithmetic), from the f64 over point of the node (its raw bits, parked in LDS) to the f64 light position.  Only the
+// second, "careful" pass of a wave over its flagged pixels calls it (render_kernel, "unsure shadow rays"), so it is a
+// real function: inlined into the any-hit walks its f64 temporaries sized the register allocation of every round
+// (profiles/r02_experiment_f64_shadow_retest.txt: +32 % frame time); as a call it costs the callers nothing until taken.
+template <bool EXOTIC>
+__device__ __attribute__((noinline)) bool shadow_exact(const DPrim* recs, const XPrim* xprims, const XExtra* xextras, const DLight* lights,
+                                                       const XLight* xlights, uint32_t prim, uint32_t ox_lo, uint32_t ox_hi, uint32_t oy_lo,
+                                                       uint32_t oy_hi, uint32_t oz_lo, uint32_t oz_hi, uint32_t li, uint32_t cell,
+                                                       uint32_t jitter_mode, uint32_t key, uint32_t node) {
+    auto dbl = [](uint32_t lo, uint32_t hi) {
+        return __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32)));
+    };
+    const D3 over = d3(dbl(ox_lo, ox_hi), dbl(oy_lo, oy_hi), dbl(oz_lo, oz_hi));
+    const DLight l = lights[li];
+    const XLight xl = xlights[li];
+    D3 lp = d3(xl.pos[0], xl.pos[1], xl.pos[2]);
+    if (l.type != RT_LIGHT_POINT) {  // light.rs:211-216
+        double ju = 0.5, jv = 0.5;
+        if (jitter_mode == RT_JITTER_COUNTER) xcounter_jitter(key, node, li, cell, ju, jv);
+        const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
+        lp = xpoint_on_light(xl, cu, cv, ju, jv);
+    }
+    const DPrim p = recs[prim];
+    return xoccludes<EXOTIC>(p.type, xprims[prim].inv, xextras[p.extra].f, over, lp);
+}
+
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
-template <bool EXOTIC, bool TREE, bool LANE>
-__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask) {
+// SOFT (the kernels with the f64 chain): the walk asks MAYBE / SURE (rt_math.h occludes_prim_soft).  A primitive that is
+// MAYBE but not SURE does not settle the ray in FP32: in a wave's first pass it is passed over and, if nothing else
+// blocks the ray, the ray is reported `unsure` (its pixel is rendered again, carefully); in the careful pass
+// `exact(prim)` gives the f64 answer on the spot.  `self_soft`: the primitive the ray starts on is such a case itself
+// (XHit::qedge).
+template <bool EXOTIC, bool TREE, bool LANE, bool SOFT, class Exact>
+__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask,
+                                         bool self_soft, bool careful, bool& unsure, Exact&& exact) {
     bool occ = false;
+    [[maybe_unused]] bool band = false;
+    [[maybe_unused]] const ShadowWin win = shadow_windows(dist);
     auto visit = [&](uint32_t prim, const DPrim& p, auto self) {
             bool hit = false;
-            if (decltype(self)::value)
-                intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
-            else
+            [[maybe_unused]] bool soft = false;
+            if constexpr (decltype(self)::value) {
+                if constexpr (SOFT) {
+                    ShadowTest st{true, false};
+                    if (!self_soft) st = occludes_self_soft<EXOTIC>(p, sc.extras, ray, dist, win);
+                    hit = st.maybe, soft = !st.sure;
+                } else {
+                    intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+                }
+            } else if constexpr (SOFT) {
+                const ShadowTest st = occludes_prim_soft<EXOTIC>(p, sc.extras, ray.o, ray.d, win);
+                hit = st.maybe, soft = !st.sure;
+            } else {
 #if RT_EXP & 16
                 hit = p.type == PRIM_SPHERE ? false : occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
 #else
                 hit = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
 #endif
+            }
             if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
+            if constexpr (SOFT) {
+                if (hit && soft) {
+                    if (careful) hit = exact(prim);
+                    else band = true, hit = false;
+                }
+            }
             occ = hit;
             return !occ;
         };
@@ -331,8 +384,10 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
     } else {
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if (sc.has_bvh) inv_d = inv_dir(ray.d);
-        traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); }, visit);
+        const float t_lo = SOFT ? win.lo_m : 0.0f, t_hi = SOFT ? win.hi_m : dist;
+        traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, t_lo, t_hi); }, visit);
     }
+    if constexpr (SOFT) unsure = band && !occ;
     return occ;
 }
 
@@ -442,6 +497,16 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     uint32_t node = 0;
     bool active = valid && sc.n_lights != 0;  // world.rs:44: a fold over no lights is BLACK
     V3 acc = v3(0.0f, 0.0f, 0.0f);
+    // Unsure shadow rays (kernels with the f64 chain).  World::is_shadowed (world.rs:73-92) is a yes/no question, and FP32
+    // cannot answer it for a ray that grazes an occluder or starts within 1e-4 of another surface (rt_math.h
+    // occludes_prim_soft); the f64 answer needs the node's f64 over point, which only a REFINED node has.  So the first
+    // pass over a tile only NOTES the pixels that met such a ray (`redo_mask`, a wave-uniform lane mask: no register
+    // per lane, nothing but a ballot in the shading loops), and the wave then renders those pixels — a few in a million
+    // — a second time, `careful`: every node refined, every such ray decided by shadow_exact from the f64 over point
+    // (its raw bits wait in six LDS rows of the lane) to the f64 light position.  A pixel is its whole path tree, so the
+    // second pass needs no state of the first: it starts from the camera ray again.
+    unsigned long long redo_mask = 0ull;
+    bool careful = false;
     // Ray stealing (kernels with path code): a lane whose pixel is finished takes over a waiting ray of another lane
     // of its wave (end of the path loop).  A lane then works for the pixel `pix` of another lane, so the colour of
     // a pixel is summed in LDS (rows 3..5 of the park area, indexed by the pixel's lane) instead of a register.
@@ -481,7 +546,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
-    __shared__ float s_park[(AREA ? 35 : 24) * kBlockThreads];
+    constexpr int kOver64Row = AREA ? 35 : 24;  // EXACT: + six rows, the raw bits of the f64 over point (careful pass)
+    __shared__ float s_park[(kOver64Row + (EXACT ? 6 : 0)) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
     if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
@@ -494,6 +560,24 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
+    // which pixel's ray a lane works on: its own, or (ray stealing) the one the ray was taken from
+    auto note_redo = [&](bool f) {
+        unsigned long long m = wave_ballot(f);
+        if (!kSteal) redo_mask |= m;
+        else
+            while (m) {
+                const int l = __ffsll(static_cast<long long>(m)) - 1;
+                m &= m - 1ull;
+                redo_mask |= 1ull << rl_u(pix, l);
+            }
+    };
+    // the f64 answer for one primitive and one shadow ray of the point whose over-point bits wait in rows `rows`
+    auto exact_shadow = [&](const float* rows, uint32_t prim, uint32_t li, uint32_t cell, uint32_t key, uint32_t at_node) {
+        auto bits = [&](int k) { return __float_as_uint(rows[(kOver64Row + k) * kBlockThreads]); };
+        return shadow_exact<EXOTIC>(sc.recs, sc.xprims, sc.xextras, sc.lights, sc.xlights, prim, bits(0), bits(1), bits(2), bits(3), bits(4), bits(5),
+                                    li, cell, P.jitter_mode, key, at_node);
+    };
+  for (;;) {
     while (wave_any(active)) {
         ++n_rounds;
 #ifdef RT_PHASE_CLOCK
@@ -557,7 +641,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 spawns = P.max_depth > level_of(node) && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
             }
             bool retry = false;
-            if (live && (hit_unsure || alt_prim != kNoPrim || spawns)) {
+            if (live && (hit_unsure || alt_prim != kNoPrim || spawns || (careful && hit_prim != kNoPrim))) {
                 const Ray64 r = cur64();
                 const uint32_t a = hit_prim, b = alt_prim;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
@@ -670,6 +754,18 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // The reference's own hit point, normal, inside flag, pattern cell and child rays; the children go
         // straight to private memory (r64[1] reflection, r64[2] refraction).
         bool tir64 = false;
+        [[maybe_unused]] bool qedge = false;  // XHit::qedge: the reference's own rounding noise decides what leaves this point
+        auto park_over64 = [&](D3 o) {
+            const double d6[3] = {o.x, o.y, o.z};
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d6[k]));
+                park[(kOver64Row + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b));
+                park[(kOver64Row + 2 * k + 1) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b >> 32));
+            }
+        };
+        if constexpr (EXACT) {
+            if (careful && has_hit) park_over64(to_d3(over));  // (a node f64 could not refine: the FP32 point, widened)
+        }
         if (EXACT && !(RT_XEXP & 2) && has_hit && (refined || late)) {
             const DPrim p = sc.recs[hit_prim];
             const DMaterial m = sc.mats[mi];
@@ -683,6 +779,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
           if (refined) {
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
+            qedge = xh.qedge;
+            if constexpr (EXACT) {
+                if (careful) park_over64(xh.over);
+            }
             // (the rays that leave this point start at the f64 point: their "self" form must stand on the same point.  The
             // FP32 hit point of a grazing ray is 1e-6 / |n . d| along the surface from it — 1e-4 in random_stress:162 —
             // and a child that itself grazes a face turns a 1e-6 offset into 1e-5 of t, random_stress:33.  Costs 1.5-3 %;
@@ -716,6 +816,12 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
           }
         }
         RT_TICK(2)
+        // first pass: such a pixel is rendered again; careful pass: its shadow rays ask f64 about the primitive itself
+        [[maybe_unused]] unsigned long long self_soft_mask = 0ull;
+        if constexpr (EXACT) {
+            if (careful) self_soft_mask = wave_ballot(qedge);
+            else note_redo(qedge);
+        }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
         auto ld3 = [&](int k) { return v3(park[k * kBlockThreads], park[(k + 1) * kBlockThreads], park[(k + 2) * kBlockThreads]); };
@@ -771,7 +877,13 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 const bool matters = sum_d != 0.0f || sum_s != 0.0f;
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
-                const bool occ = occluded<EXOTIC, TREE, LANE>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull);
+                bool unsure = false;
+                const bool occ = occluded<EXOTIC, TREE, LANE, EXACT>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull,
+                                                                     ((self_soft_mask >> lane) & 1ull) != 0ull, careful, unsure,
+                                                                     [&](uint32_t prim) { return exact_shadow(park, prim, li, 0u, 0u, 0u); });
+                if constexpr (EXACT) {
+                    if (!careful) note_redo(unsure);
+                }
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && cast && matters) c_cast++;
@@ -981,6 +1093,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         const uint32_t key = __float_as_uint(park[34 * kBlockThreads]);
                         unsigned long long occ_bits = 0ull;  // this lane's cells found occluded so far
                         bool first = true;
+                        [[maybe_unused]] bool band = false;  // EXACT: some cell met a primitive FP32 cannot settle
+                        [[maybe_unused]] const bool self_soft = ((self_soft_mask >> lane) & 1ull) != 0ull;
                         for (;;) {
                             const unsigned long long todo = wave_ballot(rem != 0);
                             if (!todo) break;
@@ -1009,9 +1123,28 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                                 sr.d = tl * inv_dist;
                                 bool hit = false;
                                 if (has && ray && !((occ_bits >> cell) & 1ull)) {
-                                    if (on_self) intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
-                                    else hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
+                                    [[maybe_unused]] bool soft = false;
+                                    if (on_self) {
+                                        if constexpr (EXACT) {
+                                            ShadowTest st{true, false};
+                                            if (!self_soft) st = occludes_self_soft<EXOTIC>(rec, sc.extras, sr, dist, shadow_windows(dist));
+                                            hit = st.maybe, soft = !st.sure;
+                                        } else {
+                                            intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+                                        }
+                                    } else if constexpr (EXACT) {
+                                        const ShadowTest st = occludes_prim_soft<EXOTIC>(rec, sc.extras, sr.o, sr.d, shadow_windows(dist));
+                                        hit = st.maybe, soft = !st.sure;
+                                    } else {
+                                        hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
+                                    }
                                     if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
+                                    if constexpr (EXACT) {
+                                        if (hit && soft) {  // (rt_kernel.h occluded<>: the same rule)
+                                            if (careful) hit = exact_shadow(park, i, li, cell, key, node);
+                                            else band = true, hit = false;
+                                        }
+                                    }
                                 }
                                 if (hit) occ_bits |= 1ull << cell;
                                 if (STATS && first && mine && ray) c_shadow++, c_cast++;
@@ -1020,6 +1153,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                             first = false;
                         }
                         if (mine) lit = static_cast<float>(cells - static_cast<uint32_t>(__popcll(occ_bits)));
+                        if constexpr (EXACT) {
+                            if (!careful) note_redo(mine && band);
+                        }
                         need = 0ull;
                     }
                 }
@@ -1058,6 +1194,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         o_node = shfl_u(node, owner);
                     }
                     unsigned int my_lit = 0;
+                    [[maybe_unused]] bool owner_unsure = false;
+                    [[maybe_unused]] const bool o_self_soft = ((self_soft_mask >> owner) & 1ull) != 0ull;
+                    [[maybe_unused]] const float* const o_rows = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
                     for (uint32_t ch = 0; ch < chunks; ++ch) {
                         const uint32_t cell = ch * 64u + sub;
                         const bool con = lane_on && cell < cells;
@@ -1082,14 +1221,23 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #if RT_EXP & 4
                         const bool occ = cast && dist > 1e30f;
 #else
-                        const bool occ = occluded<EXOTIC, TREE, LANE>(sc, sr, dist, cast, by_mask, pass_mask);
+                        bool unsure = false;
+                        const bool occ = occluded<EXOTIC, TREE, LANE, EXACT>(sc, sr, dist, cast, by_mask, pass_mask, o_self_soft, careful, unsure,
+                                                                             [&](uint32_t prim) { return exact_shadow(o_rows, prim, li, cell, o_key, o_node); });
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
+                        if constexpr (EXACT) {
+                            const unsigned long long bu = wave_ballot(unsure);
+                            if (bu && owner_now) owner_unsure |= ((bu >> lead) & gmask) != 0ull;
+                        }
                         if (STATS && cast) c_shadow++, c_cast++;
                     }
                     if (owner_now) lit = static_cast<float>(my_lit);
+                    if constexpr (EXACT) {
+                        if (!careful) note_redo(owner_now && owner_unsure);
+                    }
                 }
                 lit *= l.inv_samples;  // light.rs:208
             }
@@ -1255,6 +1403,26 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         }
         RT_TICK(4)
     }
+    if (!EXACT || careful || redo_mask == 0ull) break;
+    {
+        // The careful pass: the pixels noted above start again from their camera rays, the other lanes of the wave rest
+        // (the lane-mode kernels let them take over waiting rays as always).
+        careful = true;
+        const bool again = ((redo_mask >> lane) & 1ull) != 0ull;
+        if (again) {
+            uint32_t px, pyl, pgy;
+            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
+            camera_ray(P.cam, px, pgy, cur.o, cur.d);
+            cur.self = kNoPrim, cur.q = v3(0.0f, 0.0f, 0.0f), cur.dq = v3(0.0f, 0.0f, 0.0f);
+            w = v3(1.0f, 1.0f, 1.0f), node = 0u, acc = v3(0.0f, 0.0f, 0.0f), sp = 0, pix = lane, cur_slot = 0u;
+            if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
+            if (STATS)  // the pixel's first pass is not part of the frame: its counts go (exact without ray stealing)
+                c_primary = 1ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0, c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0,
+                c_refined = 0;
+        }
+        active = again;
+    }
+  }
 
     {
         // the pixel's coordinates are worked out again rather than kept in registers (or spilled to

@@ -269,7 +269,17 @@ RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit, Soft&& 
     int unsure = 0;
     if (self) {
         // |q| == 1 exactly by construction, so c = |q + dq|^2 - 1 = 2 q.dq + dq.dq without cancellation
-        if (!on_surface_roots(a, dot(d, q + dq), fmaf(2.0f, dot(q, dq), dot(dq, dq)), t0, t1)) return;
+        const float h = dot(d, q + dq), c = fmaf(2.0f, dot(q, dq), dot(dq, dq));
+        // A ray that leaves the sphere almost tangentially (a shadow ray at the terminator) passes the sphere it stands
+        // on at a height of the 1e-5 offset: the discriminant h^2 - a c = (|h| - s)(|h| + s), s = sqrt(a c), changes
+        // sign where |h| = s ~ 4.5e-3 |d|, and q is the true point to ~3e-7 only: within 2e-6 |d| of that it is unsure.
+        const float s = sqrt_f(fmaxf(a * c, 0.0f));
+        const bool graze = fabsf(fmaf(h, h, -(a * c))) < 4e-6f * sqrt_f(a) * (fabsf(h) + s);
+        if (!on_surface_roots(a, h, c, t0, t1)) {
+            if (graze) soft(-h * rcp_f(a));
+            return;
+        }
+        unsure = graze ? kUnsure : 0;
     } else {
         float tc, half;
         V3 l;
@@ -474,6 +484,88 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
             r.o = ro, r.d = rd, r.self = kNoPrim, r.q = v3(0.0f, 0.0f, 0.0f), r.dq = v3(0.0f, 0.0f, 0.0f);
             intersect_prim<EXOTIC>(p, extras, r, false, [&](int, float t, float, float) { occ |= in_range(t, dist); });
             return occ;
+        }
+    }
+}
+
+// What FP32 cannot settle about a shadow ray (the exact chain decides it in f64: rt_exact.h xoccludes, rt_kernel.h
+// "unsure shadow rays").  The any-hit question has three kinds of near things: a ray GRAZING a sphere or the edge of
+// a cube (kGraze, object units), a crossing within w0 of the ray's ORIGIN (the point stands within 1e-5 .. 1e-4 of
+// another surface: two cubes that touch, a body standing on the floor), a crossing within w1 of the LIGHT.  MAYBE =
+// "occludes" with every threshold moved outwards by its margin, SURE = with every threshold moved inwards: a primitive
+// that is MAYBE but not SURE is left to f64.  (The primitive a ray starts on is not asked: its self form is exact by
+// construction, rt_math.h "self".)
+struct ShadowWin {
+    float lo_m, hi_m;  // maybe: lo_m < t < hi_m
+    float lo_s, hi_s;  // sure:  lo_s < t < hi_s
+};
+RT_HD ShadowWin shadow_windows(float dist) {
+    const float w0 = amb_window(0.0f), w1 = amb_window(dist);
+    return ShadowWin{-w0, dist + w1, w0, dist - w1};
+}
+struct ShadowTest {
+    bool maybe, sure;
+};
+RT_HD bool in_win(float t, float lo, float hi) { return (t > lo) & (t < hi); }
+// The primitive the shadow ray STARTS on: its self form (rt_math.h "self") knows the crossing it stands on exactly, so
+// the plain range (0, dist) applies; what it cannot settle is a ray that grazes its own sphere (kUnsure roots, or a
+// near miss reported to `soft`).
+template <bool EXOTIC = true>
+RT_HD ShadowTest occludes_self_soft(const DPrim& p, const DExtra* extras, const Ray& ray, float dist, const ShadowWin& w) {
+    bool any = false, sure = false, near = false;
+    intersect_prim<EXOTIC>(
+        p, extras, ray, true,
+        [&](int slot, float t, float, float) {
+            const bool in = in_range(t, dist);
+            any |= in, sure |= in && !(slot & kUnsure);
+        },
+        [&](float t) { near |= in_win(t, w.lo_m, w.hi_m); });
+    return ShadowTest{any || near, sure};
+}
+template <bool EXOTIC = true>
+RT_HD ShadowTest occludes_prim_soft(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, const ShadowWin& w) {
+    switch (p.type) {
+        case PRIM_PLANE: {
+            float oy = fmaf(p.inv[4], ro.x, fmaf(p.inv[5], ro.y, fmaf(p.inv[6], ro.z, p.inv[7])));
+            float dy = fmaf(p.inv[4], rd.x, fmaf(p.inv[5], rd.y, p.inv[6] * rd.z));
+            const float t = -oy * rcp_f(dy), ady = fabsf(dy);
+            const bool maybe = !(ady <= 0.9f * kEps) & in_win(t, w.lo_m, w.hi_m), sure = !(ady <= 1.1f * kEps) & in_win(t, w.lo_s, w.hi_s);
+            return ShadowTest{maybe, sure};
+        }
+        case PRIM_SPHERE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tc, half;
+            V3 l;
+            sphere_foot(o, d, dot(d, d), tc, l, half);  // (a negative discriminant leaves half = 0: both roots at the foot)
+            const float m = 1.0f - dot(l, l);
+            const float t0 = tc - half, t1 = tc + half;
+            const bool maybe = (m > -kGraze) & (in_win(t0, w.lo_m, w.hi_m) | in_win(t1, w.lo_m, w.hi_m));
+            const bool sure = (m > kGraze) & (in_win(t0, w.lo_s, w.hi_s) | in_win(t1, w.lo_s, w.hi_s));
+            return ShadowTest{maybe, sure};
+        }
+        case PRIM_CUBE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tmin, tmax;
+            isect_box(v3(-1.0f, -1.0f, -1.0f) - o, v3(1.0f, 1.0f, 1.0f) - o, d, tmin, tmax);
+            const float room = kGraze * fmaxf(1.0f, fabsf(tmax));
+            const bool maybe = !(tmin > tmax + room) & (in_win(tmin, w.lo_m, w.hi_m) | in_win(tmax, w.lo_m, w.hi_m));
+            const bool sure = (tmax - tmin > room) & (in_win(tmin, w.lo_s, w.hi_s) | in_win(tmax, w.lo_s, w.hi_s));
+            return ShadowTest{maybe, sure};
+        }
+        default: {
+            if (!EXOTIC) return ShadowTest{false, false};
+            ShadowTest st{false, false};
+            Ray r;
+            r.o = ro, r.d = rd, r.self = kNoPrim, r.q = v3(0.0f, 0.0f, 0.0f), r.dq = v3(0.0f, 0.0f, 0.0f);
+            intersect_prim<EXOTIC>(
+                p, extras, r, false,
+                [&](int slot, float t, float, float) {
+                    st.maybe |= in_win(t, w.lo_m, w.hi_m);
+                    // (a cylinder's wall and caps report no near things of their own: its hits are never SURE)
+                    st.sure |= p.type != PRIM_CYLINDER && !(slot & kUnsure) && in_win(t, w.lo_s, w.hi_s);
+                },
+                [&](float t) { st.maybe |= in_win(t, w.lo_m, w.hi_m); });
+            return st;
         }
     }
 }

@@ -44,6 +44,7 @@ struct PackedScene {
     std::vector<XExtra> xextras;
     std::vector<double> xior;
     std::vector<XPattern> xpats;
+    std::vector<XLight> xlights;  // always filled: the caller's f64 light geometry, or the f32 values widened
     bool has_f64 = false;
     uint32_t n_items = 0, n_lights = 0;  // real counts (the vectors are padded to be non-empty)
     uint32_t max_cells = 1;              // largest usteps*vsteps over the lights
@@ -628,9 +629,16 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         l.inv_samples = 1.0f / static_cast<float>(cells);
         if (cells > out.max_cells) out.max_cells = static_cast<uint32_t>(cells);
         out.lights.push_back(l);
+        XLight xl{};
+        for (int k = 0; k < 3; ++k) {
+            xl.pos[k] = d->light_geom64 ? d->light_geom64[9 * i + k] : static_cast<double>(l.pos[k]);
+            xl.uvec[k] = d->light_geom64 ? d->light_geom64[9 * i + 3 + k] : static_cast<double>(l.uvec[k]);
+            xl.vvec[k] = d->light_geom64 ? d->light_geom64[9 * i + 6 + k] : static_cast<double>(l.vvec[k]);
+        }
+        out.xlights.push_back(xl);
     }
     out.n_lights = d->n_lights;
-    if (out.lights.empty()) out.lights.push_back(DLight{});
+    if (out.lights.empty()) out.lights.push_back(DLight{}), out.xlights.push_back(XLight{});
     return RT_OK;
 }
 

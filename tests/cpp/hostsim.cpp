@@ -102,6 +102,41 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
     });
     return occ;
 }
+// The same with the exact chain (rt_kernel.h "unsure shadow rays", occluded<> with SOFT): the walk asks MAYBE / SURE.  A
+// primitive that is MAYBE but not SURE does not settle the ray in FP32: in a pixel's first pass it is passed over and,
+// if nothing else blocks the ray, the pixel is flagged (it is rendered again, carefully); in the careful pass f64
+// answers on the spot, from the f64 over point to the f64 light position.
+std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0};
+bool occluded_soft(const Sim& s, const Ray& ray, float dist, D3 over64, D3 light64, bool self_soft, bool careful, bool& unsure) {
+    const ShadowWin w = shadow_windows(dist);
+    bool occ = false, band = false;
+    traverse(s, ray, w.lo_m, [&] { return w.hi_m; }, [&](uint32_t prim, const DPrim& p) {
+        bool hit = false, soft = false;
+        if (prim == ray.self) {
+            ShadowTest st{true, false};  // (XHit::qedge: the reference's own rounding noise decides)
+            if (!self_soft) st = occludes_self_soft(p, s.ps.extras.data(), ray, dist, w);
+            hit = st.maybe, soft = !st.sure;
+        } else {
+            const ShadowTest st = occludes_prim_soft(p, s.ps.extras.data(), ray.o, ray.d, w);
+            hit = st.maybe, soft = !st.sure;
+        }
+        hit = hit && gated_in(s, prim, ray);
+        if (hit && soft) {
+            if (careful) {
+                g_sh_f64 += 1;
+                hit = xoccludes(p.type, s.ps.xprims[prim].inv, s.ps.xextras[p.extra].f, over64, light64);
+            } else {
+                band = true, hit = false;
+            }
+        }
+        occ = hit;
+        return !occ;
+    });
+    g_sh_rays += 1;
+    unsure = band && !occ;
+    g_sh_unsure += unsure ? 1u : 0u;
+    return occ;
+}
 
 // intersection.rs:71-103 without the sorted list: a primitive is a "container" at the hit iff an
 // odd number of its intersections precede the hit; `visited.last()` is the container whose last
@@ -296,7 +331,9 @@ Closest closest_hit_fixed_window(const Sim& s, const Ray& ray) {
 std::atomic<uint64_t> g_x_nodes{0}, g_x_refined{0}, g_x_children{0}, g_x_pattern{0}, g_x_amb{0}, g_x_edge{0}, g_x_changed{0},
     g_x_retry{0};
 
-V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
+// One pass over a pixel's path tree.  `careful` = the second pass of a pixel whose first pass met a shadow ray FP32
+// could not settle (`*redo`): every node is refined and such rays are decided in f64 (rt_kernel.h "unsure shadow rays").
+V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vector<double>* trace, bool careful, bool* redo) {
     V3 acc = v3(0, 0, 0);
     if (s.ps.n_lights == 0) return acc;  // world.rs:44: fold over no lights == BLACK
     uint32_t pixel_key = jitter_pixel_key(s.seed, y * s.cam.hsize + x);
@@ -335,7 +372,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     const DMaterial& m = s.ps.mats[s.ps.recs[c.prim].material];
                     why_children = cur.depth > 0 && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
                 }
-                if (!(amb || why_children)) break;
+                if (!(amb || why_children || (careful && c.prim != kNoPrim))) break;
                 const uint32_t a = c.prim, b = c.alt;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && s.ps.order[a] < s.ps.order[b]);
                 const uint32_t first = a_first ? a : b, second = a_first ? b : a;
@@ -411,7 +448,20 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     if (!(fabsf(dist) <= kEps)) {  // null vector => not shadowed (world.rs:77-81)
                         Ray sr;
                         sr.o = over, sr.d = tl * (1.0f / dist), sr.self = hit_prim, sr.q = h.q, sr.dq = h.dq;
-                        shadowed = occluded(s, sr, dist);
+                        if (s.exact) {
+                            const XLight& xl = s.ps.xlights[li];
+                            double ju64 = 0.5, jv64 = 0.5;
+                            if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER) xcounter_jitter(pixel_key, cur.node, li, cell, ju64, jv64);
+                            const D3 lp64 = l.type == RT_LIGHT_AREA ? xpoint_on_light(xl, cu, cv, ju64, jv64) : d3(xl.pos[0], xl.pos[1], xl.pos[2]);
+                            const bool qedge = refined && xh.qedge;
+                            bool unsure = false;
+                            // (the kernel skips the rays of a light whose Phong sums are zero, shade-less materials and
+                            // points its shaft tests settle: those never flag a pixel either — their answer cannot change it)
+                            shadowed = occluded_soft(s, sr, dist, refined ? xh.over : to_d3(over), lp64, careful && qedge, careful, unsure);
+                            if (!careful && redo && (unsure || qedge)) *redo = true;
+                        } else {
+                            shadowed = occluded(s, sr, dist);
+                        }
                     }
                     if (!shadowed) ++lit;
                     V3 centre = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, 0.5f, 0.5f) : lp;
@@ -490,6 +540,17 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
         }
     }
     return acc;
+}
+V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
+    bool redo = false;
+    const size_t mark = trace ? trace->size() : 0;
+    V3 c = trace_pixel_pass(s, x, y, debug, trace, false, &redo);
+    if (s.exact && redo) {
+        g_sh_redo += 1;
+        if (trace) trace->resize(mark);
+        c = trace_pixel_pass(s, x, y, debug, trace, true, nullptr);
+    }
+    return c;
 }
 
 }  // namespace
@@ -577,6 +638,13 @@ extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc
     g_tie_audit = false;
     out[0] = g_tie_hits, out[1] = g_tie_differs, out[2] = g_tie_wide_used;
     return rc;
+}
+
+// Shadow rays of the last renders with the exact chain: out[0] = cast, out[1] = rays FP32 could not settle,
+// out[2] = primitives f64 was asked about (careful passes), out[3] = pixels rendered a second time
+extern "C" void hostsim_shadow_stats(uint64_t* out, int reset) {
+    out[0] = g_sh_rays, out[1] = g_sh_unsure, out[2] = g_sh_f64, out[3] = g_sh_redo;
+    if (reset) g_sh_rays = 0, g_sh_unsure = 0, g_sh_f64 = 0, g_sh_redo = 0;
 }
 
 // Renders like hostsim_render and reports what the exact chain did: out[0] = path nodes, out[1] = nodes refined

@@ -361,7 +361,7 @@ def test_global_rows_flag_assembles_the_frame_in_place():
     o.flags = RT_FLAG_GLOBAL_ROWS
     with pytest.raises(capi.RtError):  # host-output entry points pack their rows
         sc.render(ex.camera_desc, o)
-    o.flags = 4
+    o.flags = 8  # an unknown bit
     with pytest.raises(capi.RtError):
         sc.render_device(ex.camera_desc, frame.data_ptr(), o, 0)
     sc.close()
