@@ -120,6 +120,12 @@ struct KParams {
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
     uint32_t global_rows;  // RT_FLAG_GLOBAL_ROWS: `out` is a full frame, rows go to their global position
+    // Unsure shadow rays (kernels with the f64 chain; render_kernel "unsure shadow rays"): the pixels of this call that
+    // are rendered a second time by the CAREFUL kernel.  redo_state[0] = entries appended (may exceed redo_cap: the
+    // surplus is dropped), [1] = waves of the careful kernel that are done (the last one clears both words).
+    uint32_t* redo_queue;  // may be null; entries: packed output row * hsize + column
+    uint32_t* redo_state;
+    uint32_t redo_cap;
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
@@ -337,31 +343,36 @@ __device__ __attribute__((noinline)) bool shadow_exact(const DPrim* recs, const 
 }
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
-// SOFT (the kernels with the f64 chain): the walk asks MAYBE / SURE (rt_math.h occludes_prim_soft).  A primitive that is
-// MAYBE but not SURE does not settle the ray in FP32: in a wave's first pass it is passed over and, if nothing else
-// blocks the ray, the ray is reported `unsure` (its pixel is rendered again, carefully); in the careful pass
-// `exact(prim)` gives the f64 answer on the spot.  `self_soft`: the primitive the ray starts on is such a case itself
-// (XHit::qedge).
-template <bool EXOTIC, bool TREE, bool LANE, bool SOFT, class Exact>
+// MODE 0: the plain FP32 answer (kernels without the f64 chain).
+// MODE 1: the first pass of the kernels with the f64 chain: the plain answer, and `unsure` = some test on the way was
+//         a near thing (rt_math.h occludes_prim_near): the pixel is rendered again, carefully.
+// MODE 2: the careful pass: the walk asks MAYBE / SURE (rt_math.h occludes_prim_soft); a primitive that is MAYBE but not
+//         SURE gets its answer from f64 on the spot: exact(prim).  `self_soft`: the primitive the ray starts on is such a
+//         case itself (XHit::qedge).
+template <bool EXOTIC, bool TREE, bool LANE, int MODE, class Exact>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask,
-                                         bool self_soft, bool careful, bool& unsure, Exact&& exact) {
+                                         bool self_soft, bool& unsure, Exact&& exact) {
     bool occ = false;
-    [[maybe_unused]] bool band = false;
+    [[maybe_unused]] bool near = false;
     [[maybe_unused]] const ShadowWin win = shadow_windows(dist);
     auto visit = [&](uint32_t prim, const DPrim& p, auto self) {
             bool hit = false;
             [[maybe_unused]] bool soft = false;
             if constexpr (decltype(self)::value) {
-                if constexpr (SOFT) {
+                if constexpr (MODE == 2) {
                     ShadowTest st{true, false};
                     if (!self_soft) st = occludes_self_soft<EXOTIC>(p, sc.extras, ray, dist, win);
                     hit = st.maybe, soft = !st.sure;
+                } else if constexpr (MODE == 1) {
+                    hit = occludes_self_near<EXOTIC>(p, sc.extras, ray, dist, near);
                 } else {
                     intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
                 }
-            } else if constexpr (SOFT) {
+            } else if constexpr (MODE == 2) {
                 const ShadowTest st = occludes_prim_soft<EXOTIC>(p, sc.extras, ray.o, ray.d, win);
                 hit = st.maybe, soft = !st.sure;
+            } else if constexpr (MODE == 1) {
+                hit = occludes_prim_near<EXOTIC>(p, sc.extras, ray.o, ray.d, dist, near);
             } else {
 #if RT_EXP & 16
                 hit = p.type == PRIM_SPHERE ? false : occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
@@ -370,11 +381,8 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
 #endif
             }
             if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
-            if constexpr (SOFT) {
-                if (hit && soft) {
-                    if (careful) hit = exact(prim);
-                    else band = true, hit = false;
-                }
+            if constexpr (MODE == 2) {
+                if (hit && soft) hit = exact(prim);
             }
             occ = hit;
             return !occ;
@@ -384,10 +392,10 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
     } else {
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if (sc.has_bvh) inv_d = inv_dir(ray.d);
-        const float t_lo = SOFT ? win.lo_m : 0.0f, t_hi = SOFT ? win.hi_m : dist;
+        const float t_lo = MODE == 2 ? win.lo_m : 0.0f, t_hi = MODE == 2 ? win.hi_m : dist;
         traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, t_lo, t_hi); }, visit);
     }
-    if constexpr (SOFT) unsure = band && !occ;
+    if constexpr (MODE == 1) unsure = near;
     return occ;
 }
 
@@ -465,9 +473,15 @@ struct Ray64 {
 #ifndef RT_CONTAINER_F64
 #define RT_CONTAINER_F64 1  // experiments: 0 = the container scan never asks f64 (before the stress fuzz family)
 #endif
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true>
-__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
-    static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
+// CAREFUL = the second kernel of a frame rendered with the f64 chain: it renders the pixels the first kernel queued
+// ("unsure shadow rays" below) once more, with every node refined and every shadow ray FP32 cannot settle decided in
+// f64.  ONE PIXEL A WAVE: the pixel's path tree is shared out over the 64 lanes (ray stealing, cooperative shading),
+// so a pixel takes about as many rounds as its tree is deep, and — the queue's order differs from run to run — what a
+// wave works on never depends on another pixel.
+//
+// render_tile = one wave's work: a tile of 8x8 pixels (wave_id names its slot), or the queued pixel `redo_entry`.
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE, bool SPAWN, bool CAREFUL>
+__device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wave_id, [[maybe_unused]] const uint32_t redo_entry) {
 #ifdef RT_ORDER
     constexpr uint32_t kOrder0 = RT_ORDER;  // experiments
 #else
@@ -475,14 +489,24 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #endif
     const uint32_t kOrder = P.tile_order ? 0u : kOrder0;  // an explicit tile order names raster slots
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (wave_id >= P.n_tiles) return;
-    const uint32_t wave = P.tile_order ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
+    const uint32_t wave = (!CAREFUL && P.tile_order) ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
     uint32_t n_rounds = 0, n_visibility = 0;  // rounds of the path loop, points x light chunks that needed shadow rays: the tile's cost ("Tile order" below)
     const KScene& sc = P.sc;
 
+    // the pixel of a lane: column, row of this call's packed output, global row; false = none
+    auto lane_pixel = [&](uint32_t ln, uint32_t& px, uint32_t& pyl, uint32_t& pgy) {
+        if constexpr (CAREFUL) {  // lane 0 holds the wave's pixel
+            const uint32_t e = redo_entry;
+            pyl = e / P.cam.hsize, px = e - pyl * P.cam.hsize;
+            const uint32_t band = pyl / P.tile_rows;
+            pgy = (P.tile_first + band * P.tile_stride) * P.tile_rows + (pyl - band * P.tile_rows);
+            return ln == 0u;
+        } else {
+            return pixel_of_lane(P, kOrder, wave, ln, px, pyl, pgy);
+        }
+    };
     uint32_t x, yl, gy;
-    const bool valid = pixel_of_lane(P, kOrder, wave, lane, x, yl, gy);
+    const bool valid = lane_pixel(lane, x, yl, gy);
 
     const uint32_t pixel_key = jitter_pixel_key(P.seed, gy * P.cam.hsize + x);
     const float nlights = static_cast<float>(sc.n_lights);
@@ -500,13 +524,18 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // Unsure shadow rays (kernels with the f64 chain).  World::is_shadowed (world.rs:73-92) is a yes/no question, and FP32
     // cannot answer it for a ray that grazes an occluder or starts within 1e-4 of another surface (rt_math.h
     // occludes_prim_soft); the f64 answer needs the node's f64 over point, which only a REFINED node has.  So the first
-    // pass over a tile only NOTES the pixels that met such a ray (`redo_mask`, a wave-uniform lane mask: no register
-    // per lane, nothing but a ballot in the shading loops), and the wave then renders those pixels — a few in a million
-    // — a second time, `careful`: every node refined, every such ray decided by shadow_exact from the f64 over point
-    // (its raw bits wait in six LDS rows of the lane) to the f64 light position.  A pixel is its whole path tree, so the
-    // second pass needs no state of the first: it starts from the camera ray again.
-    unsigned long long redo_mask = 0ull;
-    bool careful = false;
+    // kernel of a frame only NOTES the pixels that met such a ray, or whose point stands within FP32 reach of a second
+    // surface (`redo_mask`, a wave-uniform lane mask: no register per lane, nothing but a compare and a ballot in the
+    // shading loops; a few pixels in ten thousand), and queues them; the CAREFUL kernel that follows renders those pixels
+    // a second time: every node refined, every such ray decided by shadow_exact from the f64 over point (its raw bits
+    // wait in six LDS rows of the lane) to the f64 light position.  A pixel is its whole path tree, so the second time
+    // needs no state of the first: it starts from the camera ray again.  (Both in ONE kernel — a second pass of the wave
+    // over its own noted pixels — measured C2 0.157 -> 0.21 ms and cover_image_area 2.0 -> 3.8 ms although 1 wave in 50
+    // took the second pass: the f64 shadow code sized the register allocation of every round,
+    // profiles/r03_unsure_shadow_rays.txt.)
+    [[maybe_unused]] unsigned long long redo_mask = 0ull;
+    constexpr bool careful = CAREFUL;
+    constexpr int kShadowMode = !EXACT ? 0 : (CAREFUL ? 2 : 1);
     // Ray stealing (kernels with path code): a lane whose pixel is finished takes over a waiting ray of another lane
     // of its wave (end of the path loop).  A lane then works for the pixel `pix` of another lane, so the colour of
     // a pixel is summed in LDS (rows 3..5 of the park area, indexed by the pixel's lane) instead of a register.
@@ -515,7 +544,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #endif
     // Only the lane-mode kernels: in a union walk the mixed depths of stolen rays widen what the wave walks together
     // (cover_image 1.20 -> 1.65 ms with stealing), in lane mode every ray walks alone anyway (profiles/r02_ray_stealing.txt).
-    constexpr bool kSteal = SPAWN && LANE && RT_STEAL != 0;
+    // The careful kernel always steals: its 63 other lanes have nothing else to do, and the one pixel of a wave is all a
+    // union walk has to cover.
+    constexpr bool kSteal = SPAWN && (LANE || CAREFUL) && RT_STEAL != 0;
     static_assert(!kSteal || kBlockThreads == 64, "ray stealing exchanges through the wave's own park rows");
     uint32_t pix = lane;
 
@@ -536,7 +567,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             // scene tables as unclobbered, and every record of the walks comes through a VECTOR load instead of
             // a scalar one — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
             uint32_t px, pyl, pgy;
-            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
+            lane_pixel(threadIdx.x & 63u, px, pyl, pgy);
             xcamera_ray(P.cam64, px, pgy, r.o, r.d);
         } else {
             r = r64[cur_slot];
@@ -546,8 +577,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
-    constexpr int kOver64Row = AREA ? 35 : 24;  // EXACT: + six rows, the raw bits of the f64 over point (careful pass)
-    __shared__ float s_park[(kOver64Row + (EXACT ? 6 : 0)) * kBlockThreads];
+    constexpr int kOver64Row = AREA ? 35 : 24;  // CAREFUL: + six rows, the raw bits of the f64 over point
+    __shared__ float s_park[(kOver64Row + (CAREFUL ? 6 : 0)) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
     if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
@@ -574,10 +605,13 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // the f64 answer for one primitive and one shadow ray of the point whose over-point bits wait in rows `rows`
     auto exact_shadow = [&](const float* rows, uint32_t prim, uint32_t li, uint32_t cell, uint32_t key, uint32_t at_node) {
         auto bits = [&](int k) { return __float_as_uint(rows[(kOver64Row + k) * kBlockThreads]); };
+#if defined(RT_SOFT_CALL) && RT_SOFT_CALL == 0  // experiment: what the call costs the callers (WRONG careful passes)
+        return bits(0) == 12345u + prim + li + cell + key + at_node;
+#else
         return shadow_exact<EXOTIC>(sc.recs, sc.xprims, sc.xextras, sc.lights, sc.xlights, prim, bits(0), bits(1), bits(2), bits(3), bits(4), bits(5),
                                     li, cell, P.jitter_mode, key, at_node);
+#endif
     };
-  for (;;) {
     while (wave_any(active)) {
         ++n_rounds;
 #ifdef RT_PHASE_CLOCK
@@ -591,6 +625,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // EXACT: what the search cannot settle in FP32 — the winner's own test was a near thing, or another
         // primitive lies within the window of the winner (or of t = 0) — is settled in f64 right after it.
         bool hit_unsure = false, refined = false;
+        [[maybe_unused]] bool contact = false;  // another surface within FP32 reach of the hit: its shadow rays start on a near thing
         uint32_t alt_prim = kNoPrim, excl0 = kNoPrim, excl1 = kNoPrim;
         float alt_t = INFINITY;
         double t64 = 0.0, u64 = 0.0, v64 = 0.0;
@@ -642,6 +677,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             }
             bool retry = false;
             if (live && (hit_unsure || alt_prim != kNoPrim || spawns || (careful && hit_prim != kNoPrim))) {
+                if constexpr (EXACT && !careful) contact |= alt_prim != kNoPrim;
                 const Ray64 r = cur64();
                 const uint32_t a = hit_prim, b = alt_prim;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
@@ -764,7 +800,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             }
         };
         if constexpr (EXACT) {
-            if (careful && has_hit) park_over64(to_d3(over));  // (a node f64 could not refine: the FP32 point, widened)
+            if constexpr (careful) {
+                if (has_hit) park_over64(to_d3(over));  // (a node f64 could not refine: the FP32 point, widened)
+            }
         }
         if (EXACT && !(RT_XEXP & 2) && has_hit && (refined || late)) {
             const DPrim p = sc.recs[hit_prim];
@@ -780,9 +818,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
             qedge = xh.qedge;
-            if constexpr (EXACT) {
-                if (careful) park_over64(xh.over);
-            }
+            if constexpr (EXACT && careful) park_over64(xh.over);
             // (the rays that leave this point start at the f64 point: their "self" form must stand on the same point.  The
             // FP32 hit point of a grazing ray is 1e-6 / |n . d| along the surface from it — 1e-4 in random_stress:162 —
             // and a child that itself grazes a face turns a 1e-6 offset into 1e-5 of t, random_stress:33.  Costs 1.5-3 %;
@@ -819,8 +855,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // first pass: such a pixel is rendered again; careful pass: its shadow rays ask f64 about the primitive itself
         [[maybe_unused]] unsigned long long self_soft_mask = 0ull;
         if constexpr (EXACT) {
-            if (careful) self_soft_mask = wave_ballot(qedge);
-            else note_redo(qedge);
+            if constexpr (careful) self_soft_mask = wave_ballot(qedge);
+            else note_redo(qedge || contact);
         }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
@@ -878,12 +914,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
                 bool unsure = false;
-                const bool occ = occluded<EXOTIC, TREE, LANE, EXACT>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull,
-                                                                     ((self_soft_mask >> lane) & 1ull) != 0ull, careful, unsure,
-                                                                     [&](uint32_t prim) { return exact_shadow(park, prim, li, 0u, 0u, 0u); });
-                if constexpr (EXACT) {
-                    if (!careful) note_redo(unsure);
-                }
+                const bool occ = occluded<EXOTIC, TREE, LANE, kShadowMode>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull,
+                                                                           ((self_soft_mask >> lane) & 1ull) != 0ull, unsure,
+                                                                           [&](uint32_t prim) { return exact_shadow(park, prim, li, 0u, 0u, 0u); });
+                if constexpr (kShadowMode == 1) note_redo(unsure);
                 lit = occ ? 0.0f : 1.0f;
                 if (STATS && cast) c_shadow++;
                 if (STATS && cast && matters) c_cast++;
@@ -1123,27 +1157,28 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                                 sr.d = tl * inv_dist;
                                 bool hit = false;
                                 if (has && ray && !((occ_bits >> cell) & 1ull)) {
-                                    [[maybe_unused]] bool soft = false;
+                                    [[maybe_unused]] bool soft = false;  // (the three modes of occluded<> above)
                                     if (on_self) {
-                                        if constexpr (EXACT) {
+                                        if constexpr (kShadowMode == 2) {
                                             ShadowTest st{true, false};
                                             if (!self_soft) st = occludes_self_soft<EXOTIC>(rec, sc.extras, sr, dist, shadow_windows(dist));
                                             hit = st.maybe, soft = !st.sure;
+                                        } else if constexpr (kShadowMode == 1) {
+                                            hit = occludes_self_near<EXOTIC>(rec, sc.extras, sr, dist, band);
                                         } else {
                                             intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
                                         }
-                                    } else if constexpr (EXACT) {
+                                    } else if constexpr (kShadowMode == 2) {
                                         const ShadowTest st = occludes_prim_soft<EXOTIC>(rec, sc.extras, sr.o, sr.d, shadow_windows(dist));
                                         hit = st.maybe, soft = !st.sure;
+                                    } else if constexpr (kShadowMode == 1) {
+                                        hit = occludes_prim_near<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist, band);
                                     } else {
                                         hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
                                     }
                                     if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
-                                    if constexpr (EXACT) {
-                                        if (hit && soft) {  // (rt_kernel.h occluded<>: the same rule)
-                                            if (careful) hit = exact_shadow(park, i, li, cell, key, node);
-                                            else band = true, hit = false;
-                                        }
+                                    if constexpr (kShadowMode == 2) {
+                                        if (hit && soft) hit = exact_shadow(park, i, li, cell, key, node);
                                     }
                                 }
                                 if (hit) occ_bits |= 1ull << cell;
@@ -1153,9 +1188,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                             first = false;
                         }
                         if (mine) lit = static_cast<float>(cells - static_cast<uint32_t>(__popcll(occ_bits)));
-                        if constexpr (EXACT) {
-                            if (!careful) note_redo(mine && band);
-                        }
+                        if constexpr (kShadowMode == 1) note_redo(mine && band);
                         need = 0ull;
                     }
                 }
@@ -1222,22 +1255,20 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         const bool occ = cast && dist > 1e30f;
 #else
                         bool unsure = false;
-                        const bool occ = occluded<EXOTIC, TREE, LANE, EXACT>(sc, sr, dist, cast, by_mask, pass_mask, o_self_soft, careful, unsure,
-                                                                             [&](uint32_t prim) { return exact_shadow(o_rows, prim, li, cell, o_key, o_node); });
+                        const bool occ = occluded<EXOTIC, TREE, LANE, kShadowMode>(sc, sr, dist, cast, by_mask, pass_mask, o_self_soft, unsure,
+                                                                                   [&](uint32_t prim) { return exact_shadow(o_rows, prim, li, cell, o_key, o_node); });
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
-                        if constexpr (EXACT) {
+                        if constexpr (kShadowMode == 1) {
                             const unsigned long long bu = wave_ballot(unsure);
                             if (bu && owner_now) owner_unsure |= ((bu >> lead) & gmask) != 0ull;
                         }
                         if (STATS && cast) c_shadow++, c_cast++;
                     }
                     if (owner_now) lit = static_cast<float>(my_lit);
-                    if constexpr (EXACT) {
-                        if (!careful) note_redo(owner_now && owner_unsure);
-                    }
+                    if constexpr (kShadowMode == 1) note_redo(owner_now && owner_unsure);
                 }
                 lit *= l.inv_samples;  // light.rs:208
             }
@@ -1403,26 +1434,6 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         }
         RT_TICK(4)
     }
-    if (!EXACT || careful || redo_mask == 0ull) break;
-    {
-        // The careful pass: the pixels noted above start again from their camera rays, the other lanes of the wave rest
-        // (the lane-mode kernels let them take over waiting rays as always).
-        careful = true;
-        const bool again = ((redo_mask >> lane) & 1ull) != 0ull;
-        if (again) {
-            uint32_t px, pyl, pgy;
-            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
-            camera_ray(P.cam, px, pgy, cur.o, cur.d);
-            cur.self = kNoPrim, cur.q = v3(0.0f, 0.0f, 0.0f), cur.dq = v3(0.0f, 0.0f, 0.0f);
-            w = v3(1.0f, 1.0f, 1.0f), node = 0u, acc = v3(0.0f, 0.0f, 0.0f), sp = 0, pix = lane, cur_slot = 0u;
-            if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
-            if (STATS)  // the pixel's first pass is not part of the frame: its counts go (exact without ray stealing)
-                c_primary = 1ull, c_reflect = 0, c_refract = 0, c_shadow = 0, c_shaded = 0, c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0,
-                c_refined = 0;
-        }
-        active = again;
-    }
-  }
 
     {
         // the pixel's coordinates are worked out again rather than kept in registers (or spilled to
@@ -1430,12 +1441,25 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         uint32_t lane_again = threadIdx.x & 63u;
         asm volatile("" : "+v"(lane_again));
         uint32_t ox, oyl, ogy;
-        if (pixel_of_lane(P, kOrder, wave, lane_again, ox, oyl, ogy)) {
+        if (lane_pixel(lane_again, ox, oyl, ogy)) {
             float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
             if (kSteal) acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }
+    if constexpr (EXACT && !CAREFUL) {
+        // queue the noted pixels for the careful kernel (one atomic a wave, and only 1 wave in 50 has any)
+        if (redo_mask != 0ull && P.redo_queue) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(P.redo_state, static_cast<uint32_t>(__popcll(redo_mask)));
+            base = uni(base);
+            uint32_t qx, qyl, qgy;
+            const bool mine = ((redo_mask >> lane) & 1ull) != 0ull && pixel_of_lane(P, kOrder, wave, lane, qx, qyl, qgy);
+            const uint32_t at = base + static_cast<uint32_t>(__popcll(redo_mask & ((1ull << lane) - 1ull)));
+            if (mine && at < P.redo_cap) P.redo_queue[at] = qyl * P.cam.hsize + qx;
+        }
+    }
+    if constexpr (CAREFUL) return;
     if (P.tile_cost) {
         uint32_t tx, tyl, tgy;
         pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
@@ -1457,6 +1481,28 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             uint32_t tx, tyl, tgy;
             pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
             if (lane == 0) P.tile_rays[(tyl >> 3) * P.tiles_x + (tx >> 3)] = static_cast<uint32_t>(cast_rays);
+        }
+    }
+}
+
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true, bool CAREFUL = false>
+__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
+    static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
+    static_assert(!CAREFUL || (EXACT && !STATS), "the careful kernel is part of the f64 chain and counts nothing");
+    const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if constexpr (!CAREFUL) {
+        if (wave_id < P.n_tiles) render_tile<STATS, EXOTIC, TREE, AREA, EXACT, LANE, SPAWN, false>(P, wave_id, 0u);
+    } else {
+        // the queued pixels, one a wave, the grid striding over the queue; every wave reports when it is done, and the
+        // last one leaves the queue empty for the next frame
+        const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+        const uint32_t queued = uni(P.redo_state[0]);
+        const uint32_t n = queued < P.redo_cap ? queued : P.redo_cap;
+#pragma unroll 1
+        for (uint32_t e = wave_id; e < n; e += n_waves) render_tile<false, EXOTIC, TREE, AREA, true, LANE, SPAWN, true>(P, e, uni(P.redo_queue[e]));
+        if ((threadIdx.x & 63u) == 0u) {
+            __threadfence();
+            if (atomicAdd(P.redo_state + 1, 1u) == n_waves - 1u) P.redo_state[0] = 0u, P.redo_state[1] = 0u;
         }
     }
 }

@@ -273,8 +273,9 @@ RT_HD void isect_sphere(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit, Soft&& 
         // A ray that leaves the sphere almost tangentially (a shadow ray at the terminator) passes the sphere it stands
         // on at a height of the 1e-5 offset: the discriminant h^2 - a c = (|h| - s)(|h| + s), s = sqrt(a c), changes
         // sign where |h| = s ~ 4.5e-3 |d|, and q is the true point to ~3e-7 only: within 2e-6 |d| of that it is unsure.
-        const float s = sqrt_f(fmaxf(a * c, 0.0f));
-        const bool graze = fabsf(fmaf(h, h, -(a * c))) < 4e-6f * sqrt_f(a) * (fabsf(h) + s);
+        // (|disc| < 2e-6 |d| (|h| + s) with |h| ~ s there, squared: no square root on this path)
+        const float disc = fmaf(h, h, -(a * c));
+        const bool graze = disc * disc < 64e-12f * a * (h * h);
         if (!on_surface_roots(a, h, c, t0, t1)) {
             if (graze) soft(-h * rcp_f(a));
             return;
@@ -486,6 +487,59 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
             return occ;
         }
     }
+}
+
+// The hot form of the question below, for the FIRST pass of the kernels with the f64 chain: the plain answer, plus
+// `near` = the ray grazes this sphere or the edge of this cube (the two near things a point in the open meets; a point
+// within 1e-4 of another surface is known from the nearest-hit search: its second candidate).  One compare a sphere,
+// four instructions a cube.
+template <bool EXOTIC = true>
+RT_HD bool occludes_prim_near(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, float dist, bool& near) {
+    switch (p.type) {
+        case PRIM_SPHERE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tc, half;
+            V3 l;
+            const bool ok = sphere_foot(o, d, dot(d, d), tc, l, half);
+            near |= fabsf(1.0f - dot(l, l)) < kGraze;
+            return ok & (in_range(tc - half, dist) | in_range(tc + half, dist));
+        }
+        case PRIM_CUBE: {
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            float tmin, tmax;
+            isect_box(v3(-1.0f, -1.0f, -1.0f) - o, v3(1.0f, 1.0f, 1.0f) - o, d, tmin, tmax);
+            near |= fabsf(tmax - tmin) <= kGraze * fmaxf(1.0f, fabsf(tmax));
+            return !(tmin > tmax) & (in_range(tmin, dist) | in_range(tmax, dist));
+        }
+        case PRIM_PLANE: return occludes_prim<EXOTIC>(p, extras, ro, rd, dist);
+        default: {
+            if (!EXOTIC) return false;
+            bool occ = false;
+            Ray r;
+            r.o = ro, r.d = rd, r.self = kNoPrim, r.q = v3(0.0f, 0.0f, 0.0f), r.dq = v3(0.0f, 0.0f, 0.0f);
+            intersect_prim<EXOTIC>(
+                p, extras, r, false,
+                [&](int slot, float t, float, float) {
+                    const bool in = in_range(t, dist);
+                    occ |= in, near |= in && (slot & kUnsure) != 0;
+                },
+                [&](float t) { near |= in_range(t, dist); });
+            return occ;
+        }
+    }
+}
+// ... and for the primitive the ray starts on: its own sphere grazed at the terminator (kUnsure roots, near misses)
+template <bool EXOTIC = true>
+RT_HD bool occludes_self_near(const DPrim& p, const DExtra* extras, const Ray& ray, float dist, bool& near) {
+    bool hit = false;
+    intersect_prim<EXOTIC>(
+        p, extras, ray, true,
+        [&](int slot, float t, float, float) {
+            const bool in = in_range(t, dist);
+            hit |= in, near |= in && (slot & kUnsure) != 0;
+        },
+        [&](float) { near = true; });
+    return hit;
 }
 
 // What FP32 cannot settle about a shadow ray (the exact chain decides it in f64: rt_exact.h xoccludes, rt_kernel.h

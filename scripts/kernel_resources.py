@@ -14,8 +14,8 @@ def one(group):
     return subprocess.run(cmd + sys.argv[1:], capture_output=True, text=True).stderr
 
 
-with ThreadPoolExecutor(6) as ex:  # one translation unit per kernel group (rt_kernels.hip)
-    err = "\n".join(ex.map(one, [0, 1, 3, 4, 5, 7]))
+with ThreadPoolExecutor(8) as ex:  # one translation unit per kernel group (rt_kernels.hip)
+    err = "\n".join(ex.map(one, [0, 1, 3, 4, 5, 7, 12, 13, 15]))
 cur = None
 rows = {}
 for line in err.splitlines():

@@ -44,7 +44,7 @@ for d in sys.argv[1:]:
         ev = np.zeros((n, 64, 24))
         cnt = np.zeros(n, dtype=np.int32)
         rgb = np.zeros((n, 3), dtype=np.float32)
-        st = (C.c_uint64 * 4)()
+        st = (C.c_uint64 * 7)()
         S.hostsim_shadow_stats(st, 1)
         rc = S.hostsim_trace_pixels(C.cast(ex.scene_desc, C.c_void_p), C.cast(ex.camera_desc, C.c_void_p), C.cast(C.byref(opt), C.c_void_p),
                                     xy.ctypes.data, n, ev.ctypes.data, 64, cnt.ctypes.data, rgb.ctypes.data)

@@ -102,39 +102,40 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
     });
     return occ;
 }
-// The same with the exact chain (rt_kernel.h "unsure shadow rays", occluded<> with SOFT): the walk asks MAYBE / SURE.  A
-// primitive that is MAYBE but not SURE does not settle the ray in FP32: in a pixel's first pass it is passed over and,
-// if nothing else blocks the ray, the pixel is flagged (it is rendered again, carefully); in the careful pass f64
-// answers on the spot, from the f64 over point to the f64 light position.
-std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0};
+// The same with the exact chain (rt_kernel.h "unsure shadow rays", occluded<> MODE 1 and 2).  First pass of a pixel: the
+// plain answer, and `unsure` = some test on the way was a near thing (a grazed sphere or cube edge, the own sphere at
+// the terminator): the pixel is rendered again, carefully.  Careful pass: the walk asks MAYBE / SURE, and a primitive that
+// is MAYBE but not SURE gets its answer from f64 on the spot, from the f64 over point to the f64 light position.
+std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0}, g_sh_why_contact{0}, g_sh_why_qedge{0}, g_sh_why_near{0};
 bool occluded_soft(const Sim& s, const Ray& ray, float dist, D3 over64, D3 light64, bool self_soft, bool careful, bool& unsure) {
     const ShadowWin w = shadow_windows(dist);
-    bool occ = false, band = false;
+    bool occ = false, near = false;
+    g_sh_rays += 1;
+    if (!careful) {
+        traverse(s, ray, 0.0f, [&] { return dist; }, [&](uint32_t prim, const DPrim& p) {
+            bool hit;
+            if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
+            else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
+            occ = hit && gated_in(s, prim, ray);
+            return !occ;
+        });
+        unsure = near;
+        g_sh_unsure += unsure ? 1u : 0u;
+        return occ;
+    }
     traverse(s, ray, w.lo_m, [&] { return w.hi_m; }, [&](uint32_t prim, const DPrim& p) {
-        bool hit = false, soft = false;
-        if (prim == ray.self) {
-            ShadowTest st{true, false};  // (XHit::qedge: the reference's own rounding noise decides)
-            if (!self_soft) st = occludes_self_soft(p, s.ps.extras.data(), ray, dist, w);
-            hit = st.maybe, soft = !st.sure;
-        } else {
-            const ShadowTest st = occludes_prim_soft(p, s.ps.extras.data(), ray.o, ray.d, w);
-            hit = st.maybe, soft = !st.sure;
-        }
-        hit = hit && gated_in(s, prim, ray);
-        if (hit && soft) {
-            if (careful) {
-                g_sh_f64 += 1;
-                hit = xoccludes(p.type, s.ps.xprims[prim].inv, s.ps.xextras[p.extra].f, over64, light64);
-            } else {
-                band = true, hit = false;
-            }
+        ShadowTest st{true, false};  // (self_soft = XHit::qedge: the reference's own rounding noise decides)
+        if (prim != ray.self) st = occludes_prim_soft(p, s.ps.extras.data(), ray.o, ray.d, w);
+        else if (!self_soft) st = occludes_self_soft(p, s.ps.extras.data(), ray, dist, w);
+        bool hit = st.maybe && gated_in(s, prim, ray);
+        if (hit && !st.sure) {
+            g_sh_f64 += 1;
+            hit = xoccludes(p.type, s.ps.xprims[prim].inv, s.ps.xextras[p.extra].f, over64, light64);
         }
         occ = hit;
         return !occ;
     });
-    g_sh_rays += 1;
-    unsure = band && !occ;
-    g_sh_unsure += unsure ? 1u : 0u;
+    unsure = false;
     return occ;
 }
 
@@ -373,6 +374,7 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
                     why_children = cur.depth > 0 && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
                 }
                 if (!(amb || why_children || (careful && c.prim != kNoPrim))) break;
+                if (!careful && redo && c.alt != kNoPrim) *redo = true, g_sh_why_contact += 1;  // another surface within FP32 reach of the hit
                 const uint32_t a = c.prim, b = c.alt;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && s.ps.order[a] < s.ps.order[b]);
                 const uint32_t first = a_first ? a : b, second = a_first ? b : a;
@@ -458,7 +460,7 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
                             // (the kernel skips the rays of a light whose Phong sums are zero, shade-less materials and
                             // points its shaft tests settle: those never flag a pixel either — their answer cannot change it)
                             shadowed = occluded_soft(s, sr, dist, refined ? xh.over : to_d3(over), lp64, careful && qedge, careful, unsure);
-                            if (!careful && redo && (unsure || qedge)) *redo = true;
+                            if (!careful && redo && (unsure || qedge)) *redo = true, g_sh_why_qedge += qedge, g_sh_why_near += unsure;
                         } else {
                             shadowed = occluded(s, sr, dist);
                         }
@@ -644,7 +646,8 @@ extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc
 // out[2] = primitives f64 was asked about (careful passes), out[3] = pixels rendered a second time
 extern "C" void hostsim_shadow_stats(uint64_t* out, int reset) {
     out[0] = g_sh_rays, out[1] = g_sh_unsure, out[2] = g_sh_f64, out[3] = g_sh_redo;
-    if (reset) g_sh_rays = 0, g_sh_unsure = 0, g_sh_f64 = 0, g_sh_redo = 0;
+    out[4] = g_sh_why_contact, out[5] = g_sh_why_qedge, out[6] = g_sh_why_near;
+    if (reset) g_sh_rays = 0, g_sh_unsure = 0, g_sh_f64 = 0, g_sh_redo = 0, g_sh_why_contact = 0, g_sh_why_qedge = 0, g_sh_why_near = 0;
 }
 
 // Renders like hostsim_render and reports what the exact chain did: out[0] = path nodes, out[1] = nodes refined
