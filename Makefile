@@ -13,7 +13,7 @@ CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -Wall -Wextra -Wno-unused-parameter -f
 CSRC     := raytracer_amd/csrc
 KHEADERS := $(CSRC)/rt_kernel.h $(CSRC)/rt_math.h $(CSRC)/rt_exact.h include/rt_amd.h
 # render_kernel's instantiations, one translation unit per group (rt_kernels.hip): they compile in parallel
-KGROUPS  := 0 1 3 4 5 7 12 13 15
+KGROUPS  := 0 1 3 4 5 7
 KOBJS    := $(KGROUPS:%=$(OBJDIR)/rt_kernels_%.o)
 
 all: product oracle testhelpers

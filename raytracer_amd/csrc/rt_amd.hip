@@ -28,9 +28,6 @@ KernelFn kernel_group_3(int variant);
 KernelFn kernel_group_4(int variant);
 KernelFn kernel_group_5(int variant);
 KernelFn kernel_group_7(int variant);
-KernelFn kernel_group_12(int variant);  // the careful kernels of groups 4, 5, 7
-KernelFn kernel_group_13(int variant);
-KernelFn kernel_group_15(int variant);
 }  // namespace rtk
 
 namespace {
@@ -155,16 +152,9 @@ struct rt_scene {
     uint32_t order_cap = 0;                       // tiles the buffer holds
     uint32_t cost_tiles = 0, cost_tiles_x = 0;    // tiling of the frame whose costs the table holds (0: none yet)
     uint32_t order_flip = 0;
-    // the pixels a frame renders a second time (rt_kernel.h "unsure shadow rays"): scenes with the f64 tables only
-    uint32_t* redo_buf = nullptr;  // [0], [1]: KParams::redo_state; from [2]: the queue, kRedoCap entries
 };
 
 namespace {
-
-// Queue of the pixels the careful kernel renders again: 2^17 entries (a 4K frame notes a few thousand; what does not
-// fit keeps its first colour).
-constexpr uint32_t kRedoCap = 1u << 17;
-constexpr uint32_t kCarefulWaves = 2048;  // grid of the careful kernel: half of what the chip holds at 4 waves per SIMD
 
 // Frames of fewer tiles than the chip holds waves at once (256 CUs x 4 SIMDs x 5) start all their tiles together anyway.
 constexpr uint32_t kOrderMinTiles = 8192;
@@ -236,18 +226,8 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
         default: break;
     }
     if (!kernel) return fail(RT_ERR_UNSUPPORTED, "no render kernel for this scene (library built with a reduced kernel set)");
-    KernelFn careful = nullptr;
-    if (exact && s->redo_buf && !std::getenv("RT_AMD_NO_CAREFUL")) {
-        careful = group == 4 ? kernel_group_12(variant) : (group == 5 ? kernel_group_13(variant) : kernel_group_15(variant));
-        if (careful) P.redo_state = s->redo_buf, P.redo_queue = s->redo_buf + 2, P.redo_cap = kRedoCap;
-    }
+    P.no_fix = std::getenv("RT_AMD_NO_FIX") ? 1u : 0u;  // (timing experiments)
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(rtk::kBlockThreads), 0, stream, P);
-    if (careful) {
-        // the second kernel of the frame: the queued pixels once more, one a wave, a fixed grid striding over the queue
-        // (its length is only known on the device); waves beyond the queue's end leave at once
-        const uint32_t waves = std::min(P.n_tiles * 64u, kCarefulWaves);
-        hipLaunchKernelGGL(careful, dim3((waves + tiles_per_block - 1u) / tiles_per_block), dim3(rtk::kBlockThreads), 0, stream, P);
-    }
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -368,11 +348,6 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(counters)");
         else s->owned.push_back(c), s->counters = static_cast<unsigned long long*>(c);
     }
-    if (rc == RT_OK && ps.has_f64) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->redo_buf), (2u + static_cast<size_t>(kRedoCap)) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(s->redo_buf, 0, 2u * sizeof(uint32_t));
-        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(redo queue)");
-    }
     if (rc == RT_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess))
         rc = fail(RT_ERR_HIP, "hipEventCreate failed");
     if (rc != RT_OK) {
@@ -388,7 +363,6 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->order_buf) (void)hipFree(s->order_buf);
-    if (s->redo_buf) (void)hipFree(s->redo_buf);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;

@@ -82,9 +82,36 @@
 #define RT_PREFETCH 0  // request record i+1 while record i is processed (costs 16 SGPR copies per record)
 #endif
 
+#ifndef RT_NO_EMIT
+#define RT_NO_EMIT 0  // experiments: 1 = no FixRecords (what writing them costs the shading loops), 2 = nor their LDS rows and private list
+#endif
+#ifndef RT_FIX_PARTS
+#define RT_FIX_PARTS 3  // experiments: bit 0 = the over_mid rows are written, bit 1 = the private record list and its flush exist
+#endif
+#ifndef RT_NO_NEAR
+#define RT_NO_NEAR 0  // experiments: 1 = the plain any-hit tests (what noting the near things costs)
+#endif
+
 namespace rtk {
 
 constexpr uint32_t kBlockThreads = RT_BLOCK_THREADS;
+
+// One (path node, light) pair whose shadow rays met a near thing in FP32 (rt_math.h occludes_prim_near): what it takes to
+// count that light's unoccluded cells again, with f64 where it matters, and to add the difference to the pixel
+// (render_kernel "unsure shadow rays").  Lives in the lane's private memory until the wave's path loop is over.
+struct FixRecord {
+    uint32_t pix;        // the pixel's lane (ray stealing: not always the lane that holds the record)
+    uint32_t light;      // light index | refined << 31
+    uint32_t node, key;  // the jitter stream of the node (rt_math.h counter_jitter)
+    float k[3];          // colour per unoccluded cell: weight x (diffuse and specular sums) / samples^2
+    float lit;           // the count the shading loop used
+    uint32_t hit_prim;
+    float over[3];       // the node's over point: FP32 value, + the next 24 bits of the f64 value of a refined node
+    float over_mid[3];
+    uint32_t scratch[5]; // (private bookkeeping of the list, rt_kernel.h `pend`)
+    double ray[6];       // a node that was not refined (and is not the camera ray's): its f64 ray
+};
+static_assert(sizeof(FixRecord) == 128, "FixRecord layout");
 
 struct KScene {
     const DPrim* recs;      // the traversal stream (rt_math.h, rt_pack.h)
@@ -120,12 +147,7 @@ struct KParams {
     uint32_t tile_rows, tile_first, tile_stride;
     uint32_t out_rows, tiles_x, n_tiles;
     uint32_t global_rows;  // RT_FLAG_GLOBAL_ROWS: `out` is a full frame, rows go to their global position
-    // Unsure shadow rays (kernels with the f64 chain; render_kernel "unsure shadow rays"): the pixels of this call that
-    // are rendered a second time by the CAREFUL kernel.  redo_state[0] = entries appended (may exceed redo_cap: the
-    // surplus is dropped), [1] = waves of the careful kernel that are done (the last one clears both words).
-    uint32_t* redo_queue;  // may be null; entries: packed output row * hsize + column
-    uint32_t* redo_state;
-    uint32_t redo_cap;
+    uint32_t no_fix;  // experiments (RT_AMD_NO_FIX): the unsure shadow rays keep their FP32 answers
 };
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
@@ -315,63 +337,20 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
     }
 }
 
-// The f64 answer for ONE primitive and ONE shadow ray (rt_exact.h xoccludes: world.rs:73-92 with the reference's own
-// arithmetic), from the f64 over point of the node (its raw bits, parked in LDS) to the f64 light position.  Only the
-// second, "careful" pass of a wave over its flagged pixels calls it (render_kernel, "unsure shadow rays"), so it is a
-// real function: inlined into the any-hit walks its f64 temporaries sized the register allocation of every round
-// (profiles/r02_experiment_f64_shadow_retest.txt: +32 % frame time); as a call it costs the callers nothing until taken.
-template <bool EXOTIC>
-__device__ __attribute__((noinline)) bool shadow_exact(const DPrim* recs, const XPrim* xprims, const XExtra* xextras, const DLight* lights,
-                                                       const XLight* xlights, uint32_t prim, uint32_t ox_lo, uint32_t ox_hi, uint32_t oy_lo,
-                                                       uint32_t oy_hi, uint32_t oz_lo, uint32_t oz_hi, uint32_t li, uint32_t cell,
-                                                       uint32_t jitter_mode, uint32_t key, uint32_t node) {
-    auto dbl = [](uint32_t lo, uint32_t hi) {
-        return __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32)));
-    };
-    const D3 over = d3(dbl(ox_lo, ox_hi), dbl(oy_lo, oy_hi), dbl(oz_lo, oz_hi));
-    const DLight l = lights[li];
-    const XLight xl = xlights[li];
-    D3 lp = d3(xl.pos[0], xl.pos[1], xl.pos[2]);
-    if (l.type != RT_LIGHT_POINT) {  // light.rs:211-216
-        double ju = 0.5, jv = 0.5;
-        if (jitter_mode == RT_JITTER_COUNTER) xcounter_jitter(key, node, li, cell, ju, jv);
-        const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
-        lp = xpoint_on_light(xl, cu, cv, ju, jv);
-    }
-    const DPrim p = recs[prim];
-    return xoccludes<EXOTIC>(p.type, xprims[prim].inv, xextras[p.extra].f, over, lp);
-}
-
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
-// MODE 0: the plain FP32 answer (kernels without the f64 chain).
-// MODE 1: the first pass of the kernels with the f64 chain: the plain answer, and `unsure` = some test on the way was
-//         a near thing (rt_math.h occludes_prim_near): the pixel is rendered again, carefully.
-// MODE 2: the careful pass: the walk asks MAYBE / SURE (rt_math.h occludes_prim_soft); a primitive that is MAYBE but not
-//         SURE gets its answer from f64 on the spot: exact(prim).  `self_soft`: the primitive the ray starts on is such a
-//         case itself (XHit::qedge).
-template <bool EXOTIC, bool TREE, bool LANE, int MODE, class Exact>
-__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask,
-                                         bool self_soft, bool& unsure, Exact&& exact) {
+// NEAR (the kernels with the f64 chain): `unsure` also reports whether some test on the way was a near thing — a grazed
+// sphere or cube edge, the own sphere at the terminator (rt_math.h occludes_prim_near): this light's count at this node
+// is then worked out again by the fix kernel.
+template <bool EXOTIC, bool TREE, bool LANE, bool NEAR>
+__device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask, bool& unsure) {
     bool occ = false;
     [[maybe_unused]] bool near = false;
-    [[maybe_unused]] const ShadowWin win = shadow_windows(dist);
     auto visit = [&](uint32_t prim, const DPrim& p, auto self) {
             bool hit = false;
-            [[maybe_unused]] bool soft = false;
             if constexpr (decltype(self)::value) {
-                if constexpr (MODE == 2) {
-                    ShadowTest st{true, false};
-                    if (!self_soft) st = occludes_self_soft<EXOTIC>(p, sc.extras, ray, dist, win);
-                    hit = st.maybe, soft = !st.sure;
-                } else if constexpr (MODE == 1) {
-                    hit = occludes_self_near<EXOTIC>(p, sc.extras, ray, dist, near);
-                } else {
-                    intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
-                }
-            } else if constexpr (MODE == 2) {
-                const ShadowTest st = occludes_prim_soft<EXOTIC>(p, sc.extras, ray.o, ray.d, win);
-                hit = st.maybe, soft = !st.sure;
-            } else if constexpr (MODE == 1) {
+                if constexpr (NEAR) hit = occludes_self_near<EXOTIC>(p, sc.extras, ray, dist, near);
+                else intersect_prim<EXOTIC>(p, sc.extras, ray, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+            } else if constexpr (NEAR) {
                 hit = occludes_prim_near<EXOTIC>(p, sc.extras, ray.o, ray.d, dist, near);
             } else {
 #if RT_EXP & 16
@@ -381,9 +360,6 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
 #endif
             }
             if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
-            if constexpr (MODE == 2) {
-                if (hit && soft) hit = exact(prim);
-            }
             occ = hit;
             return !occ;
         };
@@ -392,10 +368,35 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
     } else {
         V3 inv_d = v3(0.0f, 0.0f, 0.0f);
         if (sc.has_bvh) inv_d = inv_dir(ray.d);
-        const float t_lo = MODE == 2 ? win.lo_m : 0.0f, t_hi = MODE == 2 ? win.hi_m : dist;
-        traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, t_lo, t_hi); }, visit);
+        traverse<TREE, LANE, true>(sc, ray.self, live, ray.d, [&](uint32_t, const auto& node) { return bvh_node_hit(node, ray.o, inv_d, 0.0f, dist); }, visit);
     }
-    if constexpr (MODE == 1) unsure = near;
+    if constexpr (NEAR) unsure = near;
+    return occ;
+}
+
+// The any-hit walk of the second count ("unsure shadow rays"): one lane, one ray, the canonical stream with its skip links.
+// FP32 soft tests (rt_math.h occludes_prim_soft) where they are sure; the reference's own f64 arithmetic (rt_exact.h
+// xoccludes: world.rs:73-92) from the f64 over point to the f64 light position where they are not, and always for the
+// primitive the point stands on.
+template <bool EXOTIC>
+__device__ __forceinline__ bool fix_occluded(const KScene& sc, uint32_t self_prim, V3 o, V3 d, float dist, D3 o64, D3 lp64) {
+    const ShadowWin w = shadow_windows(dist);
+    const V3 inv_d = inv_dir(d);
+    bool occ = false;
+    for (uint32_t i = 0; i < sc.n_items && !occ;) {
+        const DPrim p = sc.recs[i];
+        if (p.type == REC_NODE) {
+            i = bvh_node_hit(p, o, inv_d, w.lo_m, w.hi_m) ? i + 1u : p.material;
+            continue;
+        }
+        ShadowTest st{true, false};
+        if (i != self_prim) st = occludes_prim_soft<EXOTIC>(p, sc.extras, o, d, w);
+        bool hit = st.maybe;
+        if (hit && sc.has_gates) hit = gates_pass(sc.gates, sc.gate[i], o, d);  // group.rs:107
+        if (hit && !st.sure) hit = xoccludes<EXOTIC>(p.type, sc.xprims[i].inv, sc.xextras[p.extra].f, o64, lp64);
+        occ = hit;
+        ++i;
+    }
     return occ;
 }
 
@@ -473,15 +474,9 @@ struct Ray64 {
 #ifndef RT_CONTAINER_F64
 #define RT_CONTAINER_F64 1  // experiments: 0 = the container scan never asks f64 (before the stress fuzz family)
 #endif
-// CAREFUL = the second kernel of a frame rendered with the f64 chain: it renders the pixels the first kernel queued
-// ("unsure shadow rays" below) once more, with every node refined and every shadow ray FP32 cannot settle decided in
-// f64.  ONE PIXEL A WAVE: the pixel's path tree is shared out over the 64 lanes (ray stealing, cooperative shading),
-// so a pixel takes about as many rounds as its tree is deep, and — the queue's order differs from run to run — what a
-// wave works on never depends on another pixel.
-//
-// render_tile = one wave's work: a tile of 8x8 pixels (wave_id names its slot), or the queued pixel `redo_entry`.
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE, bool SPAWN, bool CAREFUL>
-__device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wave_id, [[maybe_unused]] const uint32_t redo_entry) {
+template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true>
+__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
+    static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
 #ifdef RT_ORDER
     constexpr uint32_t kOrder0 = RT_ORDER;  // experiments
 #else
@@ -489,24 +484,14 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
 #endif
     const uint32_t kOrder = P.tile_order ? 0u : kOrder0;  // an explicit tile order names raster slots
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (!CAREFUL && P.tile_order) ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
+    const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave_id >= P.n_tiles) return;
+    const uint32_t wave = P.tile_order ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
     uint32_t n_rounds = 0, n_visibility = 0;  // rounds of the path loop, points x light chunks that needed shadow rays: the tile's cost ("Tile order" below)
     const KScene& sc = P.sc;
 
-    // the pixel of a lane: column, row of this call's packed output, global row; false = none
-    auto lane_pixel = [&](uint32_t ln, uint32_t& px, uint32_t& pyl, uint32_t& pgy) {
-        if constexpr (CAREFUL) {  // lane 0 holds the wave's pixel
-            const uint32_t e = redo_entry;
-            pyl = e / P.cam.hsize, px = e - pyl * P.cam.hsize;
-            const uint32_t band = pyl / P.tile_rows;
-            pgy = (P.tile_first + band * P.tile_stride) * P.tile_rows + (pyl - band * P.tile_rows);
-            return ln == 0u;
-        } else {
-            return pixel_of_lane(P, kOrder, wave, ln, px, pyl, pgy);
-        }
-    };
     uint32_t x, yl, gy;
-    const bool valid = lane_pixel(lane, x, yl, gy);
+    const bool valid = pixel_of_lane(P, kOrder, wave, lane, x, yl, gy);
 
     const uint32_t pixel_key = jitter_pixel_key(P.seed, gy * P.cam.hsize + x);
     const float nlights = static_cast<float>(sc.n_lights);
@@ -522,20 +507,15 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
     bool active = valid && sc.n_lights != 0;  // world.rs:44: a fold over no lights is BLACK
     V3 acc = v3(0.0f, 0.0f, 0.0f);
     // Unsure shadow rays (kernels with the f64 chain).  World::is_shadowed (world.rs:73-92) is a yes/no question, and FP32
-    // cannot answer it for a ray that grazes an occluder or starts within 1e-4 of another surface (rt_math.h
-    // occludes_prim_soft); the f64 answer needs the node's f64 over point, which only a REFINED node has.  So the first
-    // kernel of a frame only NOTES the pixels that met such a ray, or whose point stands within FP32 reach of a second
-    // surface (`redo_mask`, a wave-uniform lane mask: no register per lane, nothing but a compare and a ballot in the
-    // shading loops; a few pixels in ten thousand), and queues them; the CAREFUL kernel that follows renders those pixels
-    // a second time: every node refined, every such ray decided by shadow_exact from the f64 over point (its raw bits
-    // wait in six LDS rows of the lane) to the f64 light position.  A pixel is its whole path tree, so the second time
-    // needs no state of the first: it starts from the camera ray again.  (Both in ONE kernel — a second pass of the wave
-    // over its own noted pixels — measured C2 0.157 -> 0.21 ms and cover_image_area 2.0 -> 3.8 ms although 1 wave in 50
-    // took the second pass: the f64 shadow code sized the register allocation of every round,
-    // profiles/r03_unsure_shadow_rays.txt.)
-    [[maybe_unused]] unsigned long long redo_mask = 0ull;
-    constexpr bool careful = CAREFUL;
-    constexpr int kShadowMode = !EXACT ? 0 : (CAREFUL ? 2 : 1);
+    // cannot answer it for a ray that grazes an occluder, or that leaves a point whose place the reference's own rounding
+    // decides (XHit::qedge); the f64 answer needs the node's f64 over point.  A shadow ray spawns nothing: its answer only
+    // moves the count of unoccluded cells of ONE light at ONE node.  So the shading loops only NOTE that a light's rays met
+    // a near thing (one compare per sphere test), and the lane then keeps a FixRecord for that (node, light) in its
+    // private memory — the f64 over point, or the f64 ray to work it out from, and the colour one cell is worth.  When
+    // the wave's path loop is over, the wave takes the records one by one: 64 lanes count that light's cells again, a
+    // cell a lane, with soft tests + f64 (fix_occluded), and the difference goes to the pixel.  1e-4 .. 1e-3 of the nodes
+    // leave a record.  (Forms that rendered the whole PIXEL again, in this kernel or in a second one, cost 30-140 % of
+    // the frame; records in global memory for a second kernel cost 25-40 us a frame: profiles/r03_unsure_shadow_rays.txt.)
     // Ray stealing (kernels with path code): a lane whose pixel is finished takes over a waiting ray of another lane
     // of its wave (end of the path loop).  A lane then works for the pixel `pix` of another lane, so the colour of
     // a pixel is summed in LDS (rows 3..5 of the park area, indexed by the pixel's lane) instead of a register.
@@ -544,9 +524,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
 #endif
     // Only the lane-mode kernels: in a union walk the mixed depths of stolen rays widen what the wave walks together
     // (cover_image 1.20 -> 1.65 ms with stealing), in lane mode every ray walks alone anyway (profiles/r02_ray_stealing.txt).
-    // The careful kernel always steals: its 63 other lanes have nothing else to do, and the one pixel of a wave is all a
-    // union walk has to cover.
-    constexpr bool kSteal = SPAWN && (LANE || CAREFUL) && RT_STEAL != 0;
+    constexpr bool kSteal = SPAWN && LANE && RT_STEAL != 0;
     static_assert(!kSteal || kBlockThreads == 64, "ray stealing exchanges through the wave's own park rows");
     uint32_t pix = lane;
 
@@ -559,6 +537,15 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
     // competes for registers.)
     Ray64 r64[(EXACT && SPAWN) ? kStackCap + 1 : 1];
     uint32_t cur_slot = 0;
+    // EXACT: the FixRecords of this lane ("unsure shadow rays" above), until the wave's path loop is over;
+    // pend[0].scratch[0] counts them (what does not fit keeps its FP32 count).  Private memory like the stack: indexed
+    // dynamically, never in registers.
+    constexpr uint32_t kPend = 2;
+    FixRecord pend[(EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) ? kPend : 1];
+    if (EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) pend[0].scratch[0] = 0u;
+    // ... and, in three more words of pend[0] no record uses (scratch[1..3]), what the f64 over point of the
+    // current node holds beyond its FP32 value if the node was refined (private as well: three LDS rows for it cost
+    // cover_image_area a wave per CU, 2.0 -> 2.15 ms)
     auto cur64 = [&]() {
         Ray64 r;
         if (node == 0u) {
@@ -567,7 +554,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
             // scene tables as unclobbered, and every record of the walks comes through a VECTOR load instead of
             // a scalar one — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
             uint32_t px, pyl, pgy;
-            lane_pixel(threadIdx.x & 63u, px, pyl, pgy);
+            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
             xcamera_ray(P.cam64, px, pgy, r.o, r.d);
         } else {
             r = r64[cur_slot];
@@ -577,8 +564,8 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
     // slots 24..33 (area-light variants): over point, (q, dq) and primitive of the hit, read back per
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
-    constexpr int kOver64Row = AREA ? 35 : 24;  // CAREFUL: + six rows, the raw bits of the f64 over point
-    __shared__ float s_park[(kOver64Row + (CAREFUL ? 6 : 0)) * kBlockThreads];
+    constexpr bool kFix = EXACT && RT_NO_EMIT < 2;
+    __shared__ float s_park[(AREA ? 35 : 24) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
     if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
@@ -591,27 +578,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
-    // which pixel's ray a lane works on: its own, or (ray stealing) the one the ray was taken from
-    auto note_redo = [&](bool f) {
-        unsigned long long m = wave_ballot(f);
-        if (!kSteal) redo_mask |= m;
-        else
-            while (m) {
-                const int l = __ffsll(static_cast<long long>(m)) - 1;
-                m &= m - 1ull;
-                redo_mask |= 1ull << rl_u(pix, l);
-            }
-    };
-    // the f64 answer for one primitive and one shadow ray of the point whose over-point bits wait in rows `rows`
-    auto exact_shadow = [&](const float* rows, uint32_t prim, uint32_t li, uint32_t cell, uint32_t key, uint32_t at_node) {
-        auto bits = [&](int k) { return __float_as_uint(rows[(kOver64Row + k) * kBlockThreads]); };
-#if defined(RT_SOFT_CALL) && RT_SOFT_CALL == 0  // experiment: what the call costs the callers (WRONG careful passes)
-        return bits(0) == 12345u + prim + li + cell + key + at_node;
-#else
-        return shadow_exact<EXOTIC>(sc.recs, sc.xprims, sc.xextras, sc.lights, sc.xlights, prim, bits(0), bits(1), bits(2), bits(3), bits(4), bits(5),
-                                    li, cell, P.jitter_mode, key, at_node);
-#endif
-    };
     while (wave_any(active)) {
         ++n_rounds;
 #ifdef RT_PHASE_CLOCK
@@ -625,7 +591,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
         // EXACT: what the search cannot settle in FP32 — the winner's own test was a near thing, or another
         // primitive lies within the window of the winner (or of t = 0) — is settled in f64 right after it.
         bool hit_unsure = false, refined = false;
-        [[maybe_unused]] bool contact = false;  // another surface within FP32 reach of the hit: its shadow rays start on a near thing
         uint32_t alt_prim = kNoPrim, excl0 = kNoPrim, excl1 = kNoPrim;
         float alt_t = INFINITY;
         double t64 = 0.0, u64 = 0.0, v64 = 0.0;
@@ -676,8 +641,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                 spawns = P.max_depth > level_of(node) && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
             }
             bool retry = false;
-            if (live && (hit_unsure || alt_prim != kNoPrim || spawns || (careful && hit_prim != kNoPrim))) {
-                if constexpr (EXACT && !careful) contact |= alt_prim != kNoPrim;
+            if (live && (hit_unsure || alt_prim != kNoPrim || spawns)) {
                 const Ray64 r = cur64();
                 const uint32_t a = hit_prim, b = alt_prim;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
@@ -791,19 +755,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
         // straight to private memory (r64[1] reflection, r64[2] refraction).
         bool tir64 = false;
         [[maybe_unused]] bool qedge = false;  // XHit::qedge: the reference's own rounding noise decides what leaves this point
-        auto park_over64 = [&](D3 o) {
-            const double d6[3] = {o.x, o.y, o.z};
-            for (int k = 0; k < 3; ++k) {
-                const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d6[k]));
-                park[(kOver64Row + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b));
-                park[(kOver64Row + 2 * k + 1) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b >> 32));
-            }
-        };
-        if constexpr (EXACT) {
-            if constexpr (careful) {
-                if (has_hit) park_over64(to_d3(over));  // (a node f64 could not refine: the FP32 point, widened)
-            }
-        }
         if (EXACT && !(RT_XEXP & 2) && has_hit && (refined || late)) {
             const DPrim p = sc.recs[hit_prim];
             const DMaterial m = sc.mats[mi];
@@ -818,7 +769,11 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
             qedge = xh.qedge;
-            if constexpr (EXACT && careful) park_over64(xh.over);
+            if constexpr (kFix && (RT_FIX_PARTS & 1)) {  // (what the f64 over point holds beyond its FP32 value: 48 of its 53 bits travel to the fix kernel)
+                const D3 rest = xh.over - to_d3(over);
+                pend[0].scratch[1] = __float_as_uint(static_cast<float>(rest.x)), pend[0].scratch[2] = __float_as_uint(static_cast<float>(rest.y));
+                pend[0].scratch[3] = __float_as_uint(static_cast<float>(rest.z));
+            }
             // (the rays that leave this point start at the f64 point: their "self" form must stand on the same point.  The
             // FP32 hit point of a grazing ray is 1e-6 / |n . d| along the surface from it — 1e-4 in random_stress:162 —
             // and a child that itself grazes a face turns a 1e-6 offset into 1e-5 of t, random_stress:33.  Costs 1.5-3 %;
@@ -852,12 +807,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
           }
         }
         RT_TICK(2)
-        // first pass: such a pixel is rendered again; careful pass: its shadow rays ask f64 about the primitive itself
-        [[maybe_unused]] unsigned long long self_soft_mask = 0ull;
-        if constexpr (EXACT) {
-            if constexpr (careful) self_soft_mask = wave_ballot(qedge);
-            else note_redo(qedge || contact);
-        }
         // from here on the ray's origin and self data are dead; its direction is kept (eye, reflection)
         // normal, eye vector and shininess are only needed by the Phong sums: parked as well
         auto ld3 = [&](int k) { return v3(park[k * kBlockThreads], park[(k + 1) * kBlockThreads], park[(k + 2) * kBlockThreads]); };
@@ -894,10 +843,42 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
         auto h_q = [&] { return AREA ? ld3(27) : hq; };
         auto h_dq = [&] { return AREA ? ld3(30) : hdq; };
         auto h_prim = [&] { return AREA ? __float_as_uint(park[33 * kBlockThreads]) : hit_prim; };
+        // A FixRecord for a lane whose rays towards light `li` met a near thing.  It waits in the lane's PRIVATE memory until
+        // the wave ends: a store to global memory inside the path loop would make the compiler reload the scene tables
+        // after it, through vector loads (the trap of profiles/r02_exact_chain_smem_regression.txt: cover_image
+        // 1.2 -> 2.2 ms with the records written here).
+        [[maybe_unused]] auto emit_fix = [&](bool f, uint32_t li, float lit_count, float sum_d, float sum_s, V3 lc, float inv_samples) {
+            if constexpr (EXACT && !RT_NO_EMIT) {
+                if (f) {
+                    const uint32_t n = pend[0].scratch[0];
+                    if (n < kPend) {
+                        FixRecord& r = pend[n];
+                        r.pix = pix;
+                        r.light = li | (refined ? 0x80000000u : 0u);
+                        r.node = node, r.key = AREA ? __float_as_uint(park[34 * kBlockThreads]) : 0u;
+                        const V3 ec = v3(park[8 * kBlockThreads], park[9 * kBlockThreads], park[10 * kBlockThreads]) * lc;
+                        const V3 shade = ec * (park[12 * kBlockThreads] * sum_d) + lc * (park[13 * kBlockThreads] * sum_s);
+                        const V3 k = v3(park[0 * kBlockThreads], park[1 * kBlockThreads], park[2 * kBlockThreads]) * shade * (inv_samples * inv_samples);
+                        r.k[0] = k.x, r.k[1] = k.y, r.k[2] = k.z, r.lit = lit_count;
+                        r.hit_prim = h_prim();
+                        const V3 o = h_over();
+                        r.over[0] = o.x, r.over[1] = o.y, r.over[2] = o.z;
+                        r.over_mid[0] = refined ? __uint_as_float(pend[0].scratch[1]) : 0.0f, r.over_mid[1] = refined ? __uint_as_float(pend[0].scratch[2]) : 0.0f;
+                        r.over_mid[2] = refined ? __uint_as_float(pend[0].scratch[3]) : 0.0f;
+                        if (!refined && node != 0u) {  // (its ray is still where it was: only a refined node writes its children's rays early;
+                            const Ray64 rr = r64[cur_slot];  //  the camera ray is worked out from the pixel when the record leaves)
+                            r.ray[0] = rr.o.x, r.ray[1] = rr.o.y, r.ray[2] = rr.o.z, r.ray[3] = rr.d.x, r.ray[4] = rr.d.y, r.ray[5] = rr.d.z;
+                        }
+                        pend[0].scratch[0] = n + 1u;
+                    }
+                }
+            }
+        };
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             const DLight l = sc.lights[li];
             const V3 lc = v3(l.color[0], l.color[1], l.color[2]);
             float lit = 0.0f, sum_d = 0.0f, sum_s = 0.0f;
+            [[maybe_unused]] bool fix_li = false;  // EXACT: this lane's rays towards this light met a near thing
             if (!AREA || l.type == RT_LIGHT_POINT) {
                 // light.rs:182-188 + material.rs:138-159 with a single cell
                 const V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
@@ -914,11 +895,9 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
                 bool unsure = false;
-                const bool occ = occluded<EXOTIC, TREE, LANE, kShadowMode>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull,
-                                                                           ((self_soft_mask >> lane) & 1ull) != 0ull, unsure,
-                                                                           [&](uint32_t prim) { return exact_shadow(park, prim, li, 0u, 0u, 0u); });
-                if constexpr (kShadowMode == 1) note_redo(unsure);
+                const bool occ = occluded<EXOTIC, TREE, LANE, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull, unsure);
                 lit = occ ? 0.0f : 1.0f;
+                if constexpr (EXACT) emit_fix((unsure || qedge) && cast && matters, li, lit, sum_d, sum_s, lc, 1.0f);
                 if (STATS && cast) c_shadow++;
                 if (STATS && cast && matters) c_cast++;
                 if (STATS && has_hit) c_cells++;
@@ -1107,6 +1086,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                     need &= ~__ballot(dark || open || umbra);
                 }
                 if (P.tile_cost) n_visibility += static_cast<uint32_t>(__popcll(need)) * chunks;
+                [[maybe_unused]] const unsigned long long cast_mask = need;  // the lanes whose point casts rays towards this light
 
                 if (RT_EXP & 1024) need = 0;
                 // A tile with many such points (it lies in a penumbra): every lane casts its OWN
@@ -1127,8 +1107,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                         const uint32_t key = __float_as_uint(park[34 * kBlockThreads]);
                         unsigned long long occ_bits = 0ull;  // this lane's cells found occluded so far
                         bool first = true;
-                        [[maybe_unused]] bool band = false;  // EXACT: some cell met a primitive FP32 cannot settle
-                        [[maybe_unused]] const bool self_soft = ((self_soft_mask >> lane) & 1ull) != 0ull;
+                        [[maybe_unused]] bool band = false;  // EXACT: some cell met a near thing
                         for (;;) {
                             const unsigned long long todo = wave_ballot(rem != 0);
                             if (!todo) break;
@@ -1157,29 +1136,15 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                                 sr.d = tl * inv_dist;
                                 bool hit = false;
                                 if (has && ray && !((occ_bits >> cell) & 1ull)) {
-                                    [[maybe_unused]] bool soft = false;  // (the three modes of occluded<> above)
                                     if (on_self) {
-                                        if constexpr (kShadowMode == 2) {
-                                            ShadowTest st{true, false};
-                                            if (!self_soft) st = occludes_self_soft<EXOTIC>(rec, sc.extras, sr, dist, shadow_windows(dist));
-                                            hit = st.maybe, soft = !st.sure;
-                                        } else if constexpr (kShadowMode == 1) {
-                                            hit = occludes_self_near<EXOTIC>(rec, sc.extras, sr, dist, band);
-                                        } else {
-                                            intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
-                                        }
-                                    } else if constexpr (kShadowMode == 2) {
-                                        const ShadowTest st = occludes_prim_soft<EXOTIC>(rec, sc.extras, sr.o, sr.d, shadow_windows(dist));
-                                        hit = st.maybe, soft = !st.sure;
-                                    } else if constexpr (kShadowMode == 1) {
+                                        if constexpr (EXACT && !RT_NO_NEAR) hit = occludes_self_near<EXOTIC>(rec, sc.extras, sr, dist, band);
+                                        else intersect_prim<EXOTIC>(rec, sc.extras, sr, true, [&](int, float t, float, float) { hit |= in_range(t, dist); });
+                                    } else if constexpr (EXACT && !RT_NO_NEAR) {
                                         hit = occludes_prim_near<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist, band);
                                     } else {
                                         hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
                                     }
                                     if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
-                                    if constexpr (kShadowMode == 2) {
-                                        if (hit && soft) hit = exact_shadow(park, i, li, cell, key, node);
-                                    }
                                 }
                                 if (hit) occ_bits |= 1ull << cell;
                                 if (STATS && first && mine && ray) c_shadow++, c_cast++;
@@ -1188,7 +1153,7 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                             first = false;
                         }
                         if (mine) lit = static_cast<float>(cells - static_cast<uint32_t>(__popcll(occ_bits)));
-                        if constexpr (kShadowMode == 1) note_redo(mine && band);
+                        if constexpr (EXACT) fix_li |= mine && band;
                         need = 0ull;
                     }
                 }
@@ -1228,8 +1193,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                     }
                     unsigned int my_lit = 0;
                     [[maybe_unused]] bool owner_unsure = false;
-                    [[maybe_unused]] const bool o_self_soft = ((self_soft_mask >> owner) & 1ull) != 0ull;
-                    [[maybe_unused]] const float* const o_rows = s_park + (threadIdx.x & ~63u) + static_cast<uint32_t>(owner);
                     for (uint32_t ch = 0; ch < chunks; ++ch) {
                         const uint32_t cell = ch * 64u + sub;
                         const bool con = lane_on && cell < cells;
@@ -1255,21 +1218,21 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
                         const bool occ = cast && dist > 1e30f;
 #else
                         bool unsure = false;
-                        const bool occ = occluded<EXOTIC, TREE, LANE, kShadowMode>(sc, sr, dist, cast, by_mask, pass_mask, o_self_soft, unsure,
-                                                                                   [&](uint32_t prim) { return exact_shadow(o_rows, prim, li, cell, o_key, o_node); });
+                        const bool occ = occluded<EXOTIC, TREE, LANE, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast, by_mask, pass_mask, unsure);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);
                         if (owner_now) my_lit += static_cast<unsigned int>(__popcll((b >> lead) & gmask));
-                        if constexpr (kShadowMode == 1) {
+                        if constexpr (EXACT) {
                             const unsigned long long bu = wave_ballot(unsure);
                             if (bu && owner_now) owner_unsure |= ((bu >> lead) & gmask) != 0ull;
                         }
                         if (STATS && cast) c_shadow++, c_cast++;
                     }
                     if (owner_now) lit = static_cast<float>(my_lit);
-                    if constexpr (kShadowMode == 1) note_redo(owner_now && owner_unsure);
+                    if constexpr (EXACT) fix_li |= owner_now && owner_unsure;
                 }
+                if constexpr (EXACT) emit_fix(fix_li || (qedge && ((cast_mask >> lane) & 1ull) != 0ull), li, lit, sum_d, sum_s, lc, l.inv_samples);
                 lit *= l.inv_samples;  // light.rs:208
             }
             if (has_hit) {  // material.rs:127-161
@@ -1435,31 +1398,112 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
         RT_TICK(4)
     }
 
+    if constexpr (kFix && (RT_FIX_PARTS & 2)) {
+        // The second count of the lights whose rays met a near thing: the wave takes its records one by one, lane after
+        // lane, each lane's from the last to the first (one order, whatever happens around the wave).  The record goes
+        // through an LDS row (the park rows are free now) to all 64 lanes, which count the light's cells, a cell a lane.
+        uint32_t n_mine = P.no_fix ? 0u : pend[0].scratch[0];
+        float* const ex = s_park + (threadIdx.x & ~63u) + 6 * kBlockThreads;  // 32 words of row 6 (rows 3..5 may hold the pixel sums)
+#pragma unroll 1
+        for (;;) {
+            const unsigned long long mm = wave_ballot(n_mine != 0u);
+            if (mm == 0ull) break;
+            const int src = __ffsll(static_cast<long long>(mm)) - 1;
+            if (static_cast<int>(lane) == src) {
+                --n_mine;
+                const FixRecord r = pend[n_mine < kPend ? n_mine : 0u];
+                const uint32_t* wds = reinterpret_cast<const uint32_t*>(&r);
+                for (int k = 0; k < 32; ++k) ex[k] = __uint_as_float(wds[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            auto wd = [&](int k) { return uni(__float_as_uint(ex[k])); };
+            auto fl = [&](int k) { return __uint_as_float(wd(k)); };
+            auto db = [&](int k) {
+                return __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(wd(k)) | (static_cast<unsigned long long>(wd(k + 1)) << 32)));
+            };
+            const uint32_t pl = wd(0), li = wd(1) & 0x7FFFFFFFu, at_node = wd(2), key = wd(3), self_prim = wd(8);
+            const bool was_refined = (wd(1) >> 31) != 0u;
+            D3 over64 = d3(static_cast<double>(fl(9)) + static_cast<double>(fl(12)), static_cast<double>(fl(10)) + static_cast<double>(fl(13)),
+                           static_cast<double>(fl(11)) + static_cast<double>(fl(14)));
+            bool ok = li < sc.n_lights && self_prim < sc.n_items;
+            if (ok && !was_refined) {  // the node's f64 hit, worked out again from its f64 ray (intersection.rs:40-69)
+                D3 ro = d3(db(20), db(22), db(24)), rd = d3(db(26), db(28), db(30));
+                if (at_node == 0u) {
+                    uint32_t px, pyl, pgy;
+                    pixel_of_lane(P, kOrder, wave, pl, px, pyl, pgy);
+                    xcamera_ray(P.cam64, px, pgy, ro, rd);
+                }
+                const DPrim p = sc.recs[self_prim];
+                const double* xinv = sc.xprims[self_prim].inv;
+                const XHits ha = xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, ro, rd);
+                double ft = 0.0, fu = 0.0, fv = 0.0;
+                uint32_t pr = kNoPrim;
+                ok = xselect<EXOTIC>(ha, self_prim, p.type, ha, kNoPrim, REC_NODE, false, ft, pr, fu, fv);
+                if (ok) over64 = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, ro, rd, ft, fu, fv).over;
+            }
+            float delta = 0.0f;
+            if (ok) {
+                const DLight l = sc.lights[li];
+                const XLight xl = sc.xlights[li];
+                const uint32_t cells = l.usteps * l.vsteps;
+                const V3 o = to_v3(over64);
+                uint32_t lit = 0;
+#pragma unroll 1
+                for (uint32_t c0 = 0; c0 < cells; c0 += 64u) {
+                    const uint32_t cell = c0 + lane;
+                    bool unocc = false;
+                    if (cell < cells) {
+                        V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
+                        D3 lp64 = d3(xl.pos[0], xl.pos[1], xl.pos[2]);
+                        if (l.type != RT_LIGHT_POINT) {  // light.rs:211-216
+                            const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
+                            float ju = 0.5f, jv = 0.5f;
+                            double ju64 = 0.5, jv64 = 0.5;
+                            if (P.jitter_mode == RT_JITTER_COUNTER) {
+                                counter_jitter(key, at_node, li, cell, ju, jv);
+                                xcounter_jitter(key, at_node, li, cell, ju64, jv64);
+                            }
+                            lp = point_on_light(l, cu, cv, ju, jv), lp64 = xpoint_on_light(xl, cu, cv, ju64, jv64);
+                        }
+                        const V3 tl = lp - o;
+                        const float dist2 = dot(tl, tl);
+                        unocc = true;
+                        if (dist2 > 0.0f) {  // (a null vector is lit, world.rs:77-81: xoccludes decides that in f64)
+                            const float inv_dist = rsq_f(dist2);
+                            unocc = !fix_occluded<EXOTIC>(sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
+                        }
+                    }
+                    lit += static_cast<uint32_t>(__popcll(wave_ballot(unocc)));
+                }
+                delta = static_cast<float>(lit) - fl(7);
+            }
+            const V3 add = v3(fl(4), fl(5), fl(6)) * delta;
+            if (kSteal) {
+                if (static_cast<int>(lane) == src && delta != 0.0f) {
+                    atomicAdd(pixel_sum + 3 * kBlockThreads + pl, add.x);
+                    atomicAdd(pixel_sum + 4 * kBlockThreads + pl, add.y);
+                    atomicAdd(pixel_sum + 5 * kBlockThreads + pl, add.z);
+                }
+            } else if (lane == pl) {
+                acc = acc + add;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     {
         // the pixel's coordinates are worked out again rather than kept in registers (or spilled to
         // scratch) for the whole kernel; the empty asm keeps the compiler from merging the two copies
         uint32_t lane_again = threadIdx.x & 63u;
         asm volatile("" : "+v"(lane_again));
         uint32_t ox, oyl, ogy;
-        if (lane_pixel(lane_again, ox, oyl, ogy)) {
+        if (pixel_of_lane(P, kOrder, wave, lane_again, ox, oyl, ogy)) {
             float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
             if (kSteal) acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }
-    if constexpr (EXACT && !CAREFUL) {
-        // queue the noted pixels for the careful kernel (one atomic a wave, and only 1 wave in 50 has any)
-        if (redo_mask != 0ull && P.redo_queue) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P.redo_state, static_cast<uint32_t>(__popcll(redo_mask)));
-            base = uni(base);
-            uint32_t qx, qyl, qgy;
-            const bool mine = ((redo_mask >> lane) & 1ull) != 0ull && pixel_of_lane(P, kOrder, wave, lane, qx, qyl, qgy);
-            const uint32_t at = base + static_cast<uint32_t>(__popcll(redo_mask & ((1ull << lane) - 1ull)));
-            if (mine && at < P.redo_cap) P.redo_queue[at] = qyl * P.cam.hsize + qx;
-        }
-    }
-    if constexpr (CAREFUL) return;
     if (P.tile_cost) {
         uint32_t tx, tyl, tgy;
         pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
@@ -1481,28 +1525,6 @@ __device__ __forceinline__ void render_tile(const KParams& P, const uint32_t wav
             uint32_t tx, tyl, tgy;
             pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
             if (lane == 0) P.tile_rays[(tyl >> 3) * P.tiles_x + (tx >> 3)] = static_cast<uint32_t>(cast_rays);
-        }
-    }
-}
-
-template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true, bool CAREFUL = false>
-__global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
-    static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
-    static_assert(!CAREFUL || (EXACT && !STATS), "the careful kernel is part of the f64 chain and counts nothing");
-    const uint32_t wave_id = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if constexpr (!CAREFUL) {
-        if (wave_id < P.n_tiles) render_tile<STATS, EXOTIC, TREE, AREA, EXACT, LANE, SPAWN, false>(P, wave_id, 0u);
-    } else {
-        // the queued pixels, one a wave, the grid striding over the queue; every wave reports when it is done, and the
-        // last one leaves the queue empty for the next frame
-        const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-        const uint32_t queued = uni(P.redo_state[0]);
-        const uint32_t n = queued < P.redo_cap ? queued : P.redo_cap;
-#pragma unroll 1
-        for (uint32_t e = wave_id; e < n; e += n_waves) render_tile<false, EXOTIC, TREE, AREA, true, LANE, SPAWN, true>(P, e, uni(P.redo_queue[e]));
-        if ((threadIdx.x & 63u) == 0u) {
-            __threadfence();
-            if (atomicAdd(P.redo_state + 1, 1u) == n_waves - 1u) P.redo_state[0] = 0u, P.redo_state[1] = 0u;
         }
     }
 }

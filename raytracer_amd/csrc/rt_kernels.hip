@@ -6,13 +6,10 @@
 // and exports kernel_group_<g>(variant): the kernel of `variant` = 8 * counters + 4 * cylinder/triangle code +
 // 2 * hierarchy/gate code + area-light code, or nullptr where the group has none.  Lane mode only exists for the
 // hierarchy variants and always carries the path code, so the groups are 0, 1, 3, 4, 5, 7 (rt_amd.hip picks).
-// g + 8 (12, 13, 15): the CAREFUL kernels of the groups with the f64 chain — the second kernel of a frame, which renders
-// the queued pixels again (rt_kernel.h "unsure shadow rays"); they count nothing, so the variants with counters name
-// the kernels without.
 #include "rt_kernel.h"
 
 #ifndef RT_KGROUP
-#error "compile with -DRT_KGROUP=0|1|3|4|5|7|12|13|15"
+#error "compile with -DRT_KGROUP=0|1|3|4|5|7"
 #endif
 
 namespace rtk {
@@ -20,23 +17,21 @@ namespace rtk {
 using KernelFn = void (*)(const KParams);
 
 namespace {
-constexpr bool kX = (RT_KGROUP & 4) != 0, kL = (RT_KGROUP & 2) != 0, kP = (RT_KGROUP & 1) != 0, kC = (RT_KGROUP & 8) != 0;
+constexpr bool kX = (RT_KGROUP & 4) != 0, kL = (RT_KGROUP & 2) != 0, kP = (RT_KGROUP & 1) != 0;
 static_assert(!kL || kP, "lane-mode kernels always hold the path code");
-static_assert(!kC || kX, "careful kernels belong to the f64 chain");
 
 // (timing experiments on ONE family, scripts/exp_build.sh: -DRT_EXP_ONLY_TREE compiles the plain hierarchy kernels only)
 template <bool S, bool E, bool T, bool A>
 constexpr KernelFn pick() {
-    constexpr bool kS = S && !kC;
 #ifdef RT_EXP_ONLY_TREE
-    return render_kernel<kS, false, true, false, kX, kL, true, kC>;
+    return render_kernel<S, false, true, false, kX, kL, true>;
 #elif defined(RT_EXP_ONLY_FLAT_AREA)  // (the headline's kernels only)
-    return render_kernel<kS, false, false, true, kX, false, kP, kC>;
+    return render_kernel<S, false, false, true, kX, false, kP>;
 #elif defined(RT_EXP_ONLY_TREE_AREA)  // (cover_image_area's kernels only)
-    return render_kernel<kS, false, true, true, kX, false, true, kC>;
+    return render_kernel<S, false, true, true, kX, false, true>;
 #else
     if constexpr (kL && !T) return nullptr;  // lane mode needs a hierarchy
-    else return render_kernel<kS, E, T, A, kX, kL, kP, kC>;
+    else return render_kernel<S, E, T, A, kX, kL, kP>;
 #endif
 }
 }  // namespace

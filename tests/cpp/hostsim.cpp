@@ -102,31 +102,31 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
     });
     return occ;
 }
-// The same with the exact chain (rt_kernel.h "unsure shadow rays", occluded<> MODE 1 and 2).  First pass of a pixel: the
-// plain answer, and `unsure` = some test on the way was a near thing (a grazed sphere or cube edge, the own sphere at
-// the terminator): the pixel is rendered again, carefully.  Careful pass: the walk asks MAYBE / SURE, and a primitive that
-// is MAYBE but not SURE gets its answer from f64 on the spot, from the f64 over point to the f64 light position.
-std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0}, g_sh_why_contact{0}, g_sh_why_qedge{0}, g_sh_why_near{0};
-bool occluded_soft(const Sim& s, const Ray& ray, float dist, D3 over64, D3 light64, bool self_soft, bool careful, bool& unsure) {
-    const ShadowWin w = shadow_windows(dist);
-    bool occ = false, near = false;
+// The same with the exact chain (rt_kernel.h "unsure shadow rays").  The render kernel's walk: the plain answer, and
+// `near` = some test on the way was a near thing (a grazed sphere or cube edge, the own sphere at the terminator).
+std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0}, g_sh_why_qedge{0}, g_sh_why_near{0};
+bool occluded_near(const Sim& s, const Ray& ray, float dist, bool& near) {
+    bool occ = false;
     g_sh_rays += 1;
-    if (!careful) {
-        traverse(s, ray, 0.0f, [&] { return dist; }, [&](uint32_t prim, const DPrim& p) {
-            bool hit;
-            if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
-            else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
-            occ = hit && gated_in(s, prim, ray);
-            return !occ;
-        });
-        unsure = near;
-        g_sh_unsure += unsure ? 1u : 0u;
-        return occ;
-    }
+    traverse(s, ray, 0.0f, [&] { return dist; }, [&](uint32_t prim, const DPrim& p) {
+        bool hit;
+        if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
+        else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
+        occ = hit && gated_in(s, prim, ray);
+        return !occ;
+    });
+    return occ;
+}
+// The fix kernel's walk (rt_aux_kernels.h fix_occluded): FP32 soft tests where they are sure, f64 from the f64 over point
+// to the f64 light position where they are not, and always for the primitive the point stands on.
+bool occluded_fix(const Sim& s, uint32_t self_prim, V3 o, V3 d, float dist, D3 over64, D3 light64) {
+    const ShadowWin w = shadow_windows(dist);
+    Ray ray;
+    ray.o = o, ray.d = d, ray.self = kNoPrim, ray.q = v3(0, 0, 0), ray.dq = v3(0, 0, 0);
+    bool occ = false;
     traverse(s, ray, w.lo_m, [&] { return w.hi_m; }, [&](uint32_t prim, const DPrim& p) {
-        ShadowTest st{true, false};  // (self_soft = XHit::qedge: the reference's own rounding noise decides)
-        if (prim != ray.self) st = occludes_prim_soft(p, s.ps.extras.data(), ray.o, ray.d, w);
-        else if (!self_soft) st = occludes_self_soft(p, s.ps.extras.data(), ray, dist, w);
+        ShadowTest st{true, false};
+        if (prim != self_prim) st = occludes_prim_soft(p, s.ps.extras.data(), o, d, w);
         bool hit = st.maybe && gated_in(s, prim, ray);
         if (hit && !st.sure) {
             g_sh_f64 += 1;
@@ -135,7 +135,6 @@ bool occluded_soft(const Sim& s, const Ray& ray, float dist, D3 over64, D3 light
         occ = hit;
         return !occ;
     });
-    unsure = false;
     return occ;
 }
 
@@ -332,9 +331,7 @@ Closest closest_hit_fixed_window(const Sim& s, const Ray& ray) {
 std::atomic<uint64_t> g_x_nodes{0}, g_x_refined{0}, g_x_children{0}, g_x_pattern{0}, g_x_amb{0}, g_x_edge{0}, g_x_changed{0},
     g_x_retry{0};
 
-// One pass over a pixel's path tree.  `careful` = the second pass of a pixel whose first pass met a shadow ray FP32
-// could not settle (`*redo`): every node is refined and such rays are decided in f64 (rt_kernel.h "unsure shadow rays").
-V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vector<double>* trace, bool careful, bool* redo) {
+V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
     V3 acc = v3(0, 0, 0);
     if (s.ps.n_lights == 0) return acc;  // world.rs:44: fold over no lights == BLACK
     uint32_t pixel_key = jitter_pixel_key(s.seed, y * s.cam.hsize + x);
@@ -373,8 +370,7 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
                     const DMaterial& m = s.ps.mats[s.ps.recs[c.prim].material];
                     why_children = cur.depth > 0 && (!(fabsf(m.reflectivity) <= kEps) || !(fabsf(m.transparency) <= kEps));
                 }
-                if (!(amb || why_children || (careful && c.prim != kNoPrim))) break;
-                if (!careful && redo && c.alt != kNoPrim) *redo = true, g_sh_why_contact += 1;  // another surface within FP32 reach of the hit
+                if (!(amb || why_children)) break;
                 const uint32_t a = c.prim, b = c.alt;  // entered in world.objects order
                 const bool a_first = b == kNoPrim || (a != kNoPrim && s.ps.order[a] < s.ps.order[b]);
                 const uint32_t first = a_first ? a : b, second = a_first ? b : a;
@@ -438,6 +434,7 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
                 if (g_audit && l.type == RT_LIGHT_AREA) audit_shaft(s, l, li, pixel_key, cur.node, over, h, hit_prim, m.shininess);
                 uint32_t lit = 0;
                 float sum_d = 0.0f, sum_s = 0.0f;
+                bool near_any = false;
                 for (uint32_t cell = 0; cell < cells; ++cell) {
                     uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
                     float ju = 0.5f, jv = 0.5f;
@@ -450,26 +447,56 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
                     if (!(fabsf(dist) <= kEps)) {  // null vector => not shadowed (world.rs:77-81)
                         Ray sr;
                         sr.o = over, sr.d = tl * (1.0f / dist), sr.self = hit_prim, sr.q = h.q, sr.dq = h.dq;
-                        if (s.exact) {
-                            const XLight& xl = s.ps.xlights[li];
-                            double ju64 = 0.5, jv64 = 0.5;
-                            if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER) xcounter_jitter(pixel_key, cur.node, li, cell, ju64, jv64);
-                            const D3 lp64 = l.type == RT_LIGHT_AREA ? xpoint_on_light(xl, cu, cv, ju64, jv64) : d3(xl.pos[0], xl.pos[1], xl.pos[2]);
-                            const bool qedge = refined && xh.qedge;
-                            bool unsure = false;
-                            // (the kernel skips the rays of a light whose Phong sums are zero, shade-less materials and
-                            // points its shaft tests settle: those never flag a pixel either — their answer cannot change it)
-                            shadowed = occluded_soft(s, sr, dist, refined ? xh.over : to_d3(over), lp64, careful && qedge, careful, unsure);
-                            if (!careful && redo && (unsure || qedge)) *redo = true, g_sh_why_qedge += qedge, g_sh_why_near += unsure;
-                        } else {
-                            shadowed = occluded(s, sr, dist);
-                        }
+                        if (s.exact) shadowed = occluded_near(s, sr, dist, near_any);
+                        else shadowed = occluded(s, sr, dist);
                     }
                     if (!shadowed) ++lit;
                     V3 centre = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, 0.5f, 0.5f) : lp;
                     float ldn, spec;
                     phong_cell(phong_point(over, h.n, h.eye, m.shininess), centre, ldn, spec);
                     sum_d += ldn, sum_s += spec;
+                }
+                if (s.exact && (near_any || (refined && xh.qedge))) {
+                    // rt_kernel.h "unsure shadow rays": a FixRecord, and the fix kernel counts this light's cells again
+                    g_sh_redo += 1, g_sh_why_near += near_any, g_sh_why_qedge += refined && xh.qedge;
+                    D3 over64;
+                    bool ok = true;
+                    if (refined) {  // (48 of the 53 bits travel: FixRecord::over + over_mid)
+                        const D3 rest = xh.over - to_d3(over);
+                        const V3 mid = to_v3(rest);
+                        over64 = d3(static_cast<double>(over.x) + static_cast<double>(mid.x), static_cast<double>(over.y) + static_cast<double>(mid.y),
+                                    static_cast<double>(over.z) + static_cast<double>(mid.z));
+                    } else {  // the node's f64 hit, worked out again from its f64 ray
+                        const XHits ha = xintersect(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64);
+                        double ft = 0.0, fu = 0.0, fv = 0.0;
+                        uint32_t pr = kNoPrim;
+                        ok = xselect<true>(ha, hit_prim, p.type, ha, kNoPrim, REC_NODE, false, ft, pr, fu, fv);
+                        if (ok) over64 = xprepare(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64, ft, fu, fv).over;
+                    }
+                    if (ok) {
+                        const XLight& xl = s.ps.xlights[li];
+                        const V3 o = to_v3(over64);
+                        lit = 0;
+                        for (uint32_t cell = 0; cell < cells; ++cell) {
+                            const uint32_t cu = cell % l.usteps, cv = cell / l.usteps;
+                            float ju = 0.5f, jv = 0.5f;
+                            double ju64 = 0.5, jv64 = 0.5;
+                            if (l.type == RT_LIGHT_AREA && s.jitter_mode == RT_JITTER_COUNTER) {
+                                counter_jitter(pixel_key, cur.node, li, cell, ju, jv);
+                                xcounter_jitter(pixel_key, cur.node, li, cell, ju64, jv64);
+                            }
+                            const V3 lp = l.type == RT_LIGHT_AREA ? point_on_light(l, cu, cv, ju, jv) : v3(l.pos[0], l.pos[1], l.pos[2]);
+                            const D3 lp64 = l.type == RT_LIGHT_AREA ? xpoint_on_light(xl, cu, cv, ju64, jv64) : d3(xl.pos[0], xl.pos[1], xl.pos[2]);
+                            const V3 tl = lp - o;
+                            const float dist2 = dot(tl, tl);
+                            bool unocc = true;
+                            if (dist2 > 0.0f) {
+                                const float inv_dist = rsq_f(dist2);
+                                unocc = !occluded_fix(s, hit_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
+                            }
+                            lit += unocc ? 1u : 0u;
+                        }
+                    }
                 }
                 float intensity = static_cast<float>(lit) * l.inv_samples;
                 if (li < 4) lit_by_light[li] = intensity;
@@ -543,18 +570,6 @@ V3 trace_pixel_pass(const Sim& s, uint32_t x, uint32_t y, bool debug, std::vecto
     }
     return acc;
 }
-V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::vector<double>* trace = nullptr) {
-    bool redo = false;
-    const size_t mark = trace ? trace->size() : 0;
-    V3 c = trace_pixel_pass(s, x, y, debug, trace, false, &redo);
-    if (s.exact && redo) {
-        g_sh_redo += 1;
-        if (trace) trace->resize(mark);
-        c = trace_pixel_pass(s, x, y, debug, trace, true, nullptr);
-    }
-    return c;
-}
-
 }  // namespace
 
 extern "C" int hostsim_render(const rt_scene_desc* desc, const rt_camera_desc* camera, const rt_options* options,
@@ -642,12 +657,12 @@ extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc
     return rc;
 }
 
-// Shadow rays of the last renders with the exact chain: out[0] = cast, out[1] = rays FP32 could not settle,
-// out[2] = primitives f64 was asked about (careful passes), out[3] = pixels rendered a second time
+// Shadow rays of the last renders with the exact chain: out[0] = cast, out[2] = primitives f64 was asked about,
+// out[3] = (node, light) pairs counted again, out[5] / out[6] = of those: because of a quirk-edge hit / a near thing
 extern "C" void hostsim_shadow_stats(uint64_t* out, int reset) {
     out[0] = g_sh_rays, out[1] = g_sh_unsure, out[2] = g_sh_f64, out[3] = g_sh_redo;
-    out[4] = g_sh_why_contact, out[5] = g_sh_why_qedge, out[6] = g_sh_why_near;
-    if (reset) g_sh_rays = 0, g_sh_unsure = 0, g_sh_f64 = 0, g_sh_redo = 0, g_sh_why_contact = 0, g_sh_why_qedge = 0, g_sh_why_near = 0;
+    out[4] = 0, out[5] = g_sh_why_qedge, out[6] = g_sh_why_near;
+    if (reset) g_sh_rays = 0, g_sh_unsure = 0, g_sh_f64 = 0, g_sh_redo = 0, g_sh_why_qedge = 0, g_sh_why_near = 0;
 }
 
 // Renders like hostsim_render and reports what the exact chain did: out[0] = path nodes, out[1] = nodes refined
