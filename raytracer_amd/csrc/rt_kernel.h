@@ -540,7 +540,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // EXACT: the FixRecords of this lane ("unsure shadow rays" above), until the wave's path loop is over;
     // pend[0].scratch[0] counts them (what does not fit keeps its FP32 count).  Private memory like the stack: indexed
     // dynamically, never in registers.
-    constexpr uint32_t kPend = 2;
+#ifndef RT_PEND
+#define RT_PEND 2  // (not 1: a one-element array is indexed by a constant and moves into 32 registers — C4 7.4 -> 9.7 ms)
+#endif
+    constexpr uint32_t kPend = RT_PEND;
     FixRecord pend[(EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) ? kPend : 1];
     if (EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) pend[0].scratch[0] = 0u;
     // ... and, in three more words of pend[0] no record uses (scratch[1..3]), what the f64 over point of the
@@ -848,8 +851,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // after it, through vector loads (the trap of profiles/r02_exact_chain_smem_regression.txt: cover_image
         // 1.2 -> 2.2 ms with the records written here).
         [[maybe_unused]] auto emit_fix = [&](bool f, uint32_t li, float lit_count, float sum_d, float sum_s, V3 lc, float inv_samples) {
+#ifndef RT_EMIT_HINT
+#define RT_EMIT_HINT 1  // the record code is laid out as the unlikely side (cover_image_area 2.61 -> 2.40 ms)
+#endif
             if constexpr (EXACT && !RT_NO_EMIT) {
-                if (f) {
+                if (RT_EMIT_HINT ? __builtin_expect(f, false) : f) {
                     const uint32_t n = pend[0].scratch[0];
                     if (n < kPend) {
                         FixRecord& r = pend[n];
