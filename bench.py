@@ -46,6 +46,9 @@ Rank 0 prints ONE JSON line.
   first_frame_kernel_ms  the kernel time of the FIRST frame of a fresh scene object: scenes with glass start the
             expensive tiles of a frame first once the previous frame has measured them; a single-shot
             render gets this number, the timed loop the steady state.
+  render_call_ms  the reference's own call shape, `camera.render(&world)` of a caller that keeps nothing: wall clock of
+            rt_scene_create + rt_render (or rt_render_u8, `.to_image()` included) + rt_scene_destroy on rank 0, split
+            into create / render (kernel inside) / destroy, and the same render call repeated on the kept scene.
   cpu_baseline  the f64 oracle (a restatement of the reference algorithm, NOT the Rust binary) on this host.
 """
 from __future__ import annotations
@@ -226,6 +229,32 @@ class Job:
         t = torch.tensor([v], dtype=torch.float64, device=self.ctl)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+
+def one_shot_calls(ex: ExampleScene, device: int, opt: RtOptions) -> dict:
+    """`camera.render(&world)` as ONE call of a caller that keeps nothing (the reference's API, camera.rs:108): wall clock of
+    rt_scene_create + rt_render + rt_scene_destroy on a whole frame, split into its parts, for the float canvas
+    (rt_render) and for the byte image (`.to_image()` included, rt_render_u8); `again_*` = the same call repeated on the
+    scene it already has (tile costs known, device image in place).  Median of 3, whole frames on this GPU."""
+    def once(u8: bool):
+        t0 = time.perf_counter()
+        sc = Scene(ex.scene_desc, device)
+        t1 = time.perf_counter()
+        _, st = (sc.render_u8 if u8 else sc.render)(ex.camera_desc, opt)
+        t2 = time.perf_counter()
+        _, st2 = (sc.render_u8 if u8 else sc.render)(ex.camera_desc, opt)
+        t3 = time.perf_counter()
+        sc.close()
+        t4 = time.perf_counter()
+        return {"total_ms": (t2 - t0 + t4 - t3) * 1e3, "create_ms": (t1 - t0) * 1e3, "render_ms": (t2 - t1) * 1e3,
+                "kernel_ms": float(st.kernel_ms), "destroy_ms": (t4 - t3) * 1e3, "again_render_ms": (t3 - t2) * 1e3,
+                "again_kernel_ms": float(st2.kernel_ms)}
+
+    out = {}
+    for key, u8 in (("f32_canvas", False), ("u8_image", True)):
+        runs = [once(u8) for _ in range(3)]
+        out[key] = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
+    return out
 
 
 def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmup: int, sustain_s: float) -> dict:
@@ -410,11 +439,13 @@ def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmu
     # The FIRST frame of a scene runs in raster order (no measured tile costs yet): a fresh scene object,
     # one frame of this rank's share, untimed by the loop above and reported beside the steady state.
     first_kernel_ms = None
+    render_call = None
     if rank == 0:
         fresh = Scene(ex.scene_desc, job.local_rank)
         _, st_first = fresh.render(ex.camera_desc, opt)
         first_kernel_ms = float(st_first.kernel_ms)
         fresh.close()
+        render_call = one_shot_calls(ex, job.local_rank, base)
 
     rep = None
     if rank == 0:
@@ -422,7 +453,7 @@ def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmu
         rep = {
             "workload": f"examples/{name} at {width}x{height}, jitter={args.jitter} seed={args.seed}, RECURSION_DEPTH=5, "
                         f"{'FP32 only' if args.f32_only else 'f64 chain on'}",
-            "frame_ms": ms, "kernel_ms": kernel_ms, "first_frame_kernel_ms": first_kernel_ms, "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
+            "frame_ms": ms, "kernel_ms": kernel_ms, "first_frame_kernel_ms": first_kernel_ms, "render_call_ms": render_call, "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
             "assembled_frame_equals_single_gpu_frame": verified, "sustained": sustained,
             "rays_per_frame": total_rays, "rays_cast": rays_cast, "cast_share": rays_cast / max(1, total_rays),
             "rays_by_kind": total, "mrays_per_s": total_rays / (ms * 1e-3) / 1e6, "mrays_cast_per_s": rays_cast / (ms * 1e-3) / 1e6,
@@ -456,7 +487,7 @@ def main():
             w, h = WORKLOADS[name]
             r = run_workload(job, name, w, h, steps=5, warmup=1, sustain_s=0.0)
             if r is not None:
-                also[name] = {k: r[k] for k in ("workload", "frame_ms", "kernel_ms", "first_frame_kernel_ms", "assembly", "assembled_frame_equals_single_gpu_frame",
+                also[name] = {k: r[k] for k in ("workload", "frame_ms", "kernel_ms", "first_frame_kernel_ms", "render_call_ms", "assembly", "assembled_frame_equals_single_gpu_frame",
                                                 "rays_per_frame", "rays_cast", "mrays_per_s", "mrays_cast_per_s", "kernel")}
 
     if job.rank == 0:
@@ -500,6 +531,7 @@ def main():
             "frame_ms": head["frame_ms"],
             "kernel_ms": kernel_ms,
             "first_frame_kernel_ms": head["first_frame_kernel_ms"],
+            "render_call_ms": head["render_call_ms"],
             "sustained": head["sustained"],
             "roofline": {
                 "bound": "valu_fp32", "achieved": hw["executed_tflops"], "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -139,6 +139,14 @@ extern "C" {
         rgb_out_host: *mut f32,
         stats_out: *mut rt_stats,
     ) -> c_int;
+    pub fn rt_render_u8(
+        scene: *mut rt_scene,
+        camera: *const rt_camera_desc,
+        options: *const rt_options,
+        rgb8_out_host: *mut u8,
+        stats_out: *mut rt_stats,
+    ) -> c_int;
+    pub fn rt_scene_reserve(scene: *mut rt_scene, hsize: u32, rows: u32) -> c_int;
     pub fn rt_render_stats(
         scene: *mut rt_scene,
         camera: *const rt_camera_desc,

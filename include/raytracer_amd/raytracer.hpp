@@ -674,6 +674,28 @@ struct Camera {
         if (rc != RT_OK) throw Error(rt_last_error());
         return canvas;
     }
+    // `camera.render(&world).to_image()` — the last two lines of every example of the reference (e.g.
+    // examples/cover-image.rs:196) — as ONE call: the frame is quantised on the GPU (canvas.rs:31-45) and a byte per
+    // channel crosses PCIe instead of a float.  rows x hsize x 3 bytes, row 0 = top.
+    std::vector<uint8_t> render_image(const World& world, const rt_options* options = nullptr, int device = 0, rt_stats* stats = nullptr) const {
+        FlatScene flat = flatten(world);
+        rt_scene_desc sd = flat.desc();
+        rt_scene* scene = nullptr;
+        if (rt_scene_create(&sd, device, &scene) != RT_OK) throw Error(rt_last_error());
+        rt_camera_desc cd = desc();
+        rt_options opt{};
+        if (options) opt = *options;
+        uint32_t rows = 0;
+        if (rt_output_rows(&cd, &opt, &rows) != RT_OK) {
+            rt_scene_destroy(scene);
+            throw Error(rt_last_error());
+        }
+        std::vector<uint8_t> img(static_cast<size_t>(rows) * hsize * 3, 0);
+        int rc = rt_render_u8(scene, &cd, &opt, img.data(), stats);
+        rt_scene_destroy(scene);
+        if (rc != RT_OK) throw Error(rt_last_error());
+        return img;
+    }
 };
 
 struct Scene {

@@ -200,6 +200,14 @@ int rt_device_count(int* count_out);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* ABI 3.  Sets the scene up for frames of up to `hsize` x `rows` pixels ahead of time: the tile-cost table of a
+ * scene with transparent materials (rt_render_device below) and the device image the host-output entry points
+ * keep.  After it, rt_render_device never allocates or waits for frames up to that size, and rt_render /
+ * rt_render_u8 / rt_render_stats call no hipMalloc either.  Optional: without it the first call of a size does
+ * the same work itself.  No counterpart in the reference (Camera::render allocates its Canvas per call,
+ * camera.rs:164). */
+int rt_scene_reserve(rt_scene* scene, uint32_t hsize, uint32_t rows);
+
 /* Which instantiation of the render kernel the scene runs — render_kernel<counters, EXOTIC, TREE, AREA,
  * F64, LANE, SPAWN> in rocprofv3 output: RT_VARIANT_* bits (profiling and bench reports; no counterpart in the
  * reference).  F64 says the scene carries the f64 tables; the kernel with the f64 chain runs when the
@@ -229,12 +237,20 @@ int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint
  *                     (RT_AMD_NO_TILE_ORDER=1 in the environment: never).  Calls on one scene must be
  *                     ordered on the device as well (one stream, or events between streams).
  *                     rt_render_stats_noalloc never allocates and does not reorder.
- *   rt_render:        rgb_out is HOST memory; the call allocates a device image, renders, copies
- *                     back and waits.  stats_out may be NULL. */
+ *   rt_render:        rgb_out is HOST memory; the call renders into a device image the scene keeps (allocated
+ *                     on the first call of a size, or by rt_scene_reserve), copies back and waits.
+ *                     stats_out may be NULL.
+ *   rt_render_u8:     (ABI 3) Camera::render followed by Canvas::to_image (canvas.rs:31-45) in one call, for
+ *                     callers that only want the 8-bit image — what every example of the reference does
+ *                     (examples/*.rs: `camera.render(&world).to_image()`): the frame is quantised on the device
+ *                     and ONE byte per channel crosses PCIe instead of four.  rgb8_out_host: rows * hsize * 3
+ *                     bytes.  Bit-identical to rt_render + rt_quantize_u8. */
 int rt_render_device(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
                      float* rgb_out_device, void* stream);
 int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host,
               rt_stats* stats_out);
+int rt_render_u8(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, uint8_t* rgb8_out_host,
+                 rt_stats* stats_out);
 /* Same image, plus the counters (uses the instrumented kernel variant; slower). rgb may be NULL. */
 int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,
                     float* rgb_out_host, rt_stats* stats_out);

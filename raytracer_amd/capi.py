@@ -81,7 +81,8 @@ class RtStats(C.Structure):
 # Every symbol include/rt_amd.h declares (tests check that the library exports all of them).
 RT_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_variant",
-    "rt_output_rows", "rt_render_device", "rt_render", "rt_render_stats", "rt_render_stats_noalloc", "rt_quantize_u8_device",
+    "rt_output_rows", "rt_render_device", "rt_render", "rt_render_u8", "rt_scene_reserve", "rt_render_stats", "rt_render_stats_noalloc",
+    "rt_quantize_u8_device",
     "rt_quantize_u8", "rt_frame_create", "rt_frame_open", "rt_frame_close", "rt_frame_destroy", "rt_frame_download",
 ]
 
@@ -114,6 +115,8 @@ def lib() -> C.CDLL:
         L.rt_output_rows.argtypes = [C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.POINTER(C.c_uint32)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
+        L.rt_render_u8.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
+        L.rt_scene_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.rt_render_stats.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
         L.rt_render_stats_noalloc.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p,
                                               C.POINTER(RtStats), C.c_void_p]
@@ -148,6 +151,8 @@ def scenes_lib() -> C.CDLL:
         S.rtx_scene_free.restype = None
         S.rtx_render_example.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(RtOptions), C.c_int, C.c_void_p,
                                          C.POINTER(RtStats)]
+        S.rtx_render_example_u8.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(RtOptions), C.c_int, C.c_void_p,
+                                            C.POINTER(RtStats)]
         S.rtx_scene_name.restype = C.c_char_p
         S.rtx_render_example_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(RtOptions), C.c_int, C.c_char_p]
         S.rtx_png_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -221,6 +226,20 @@ class Scene:
         _check(fn(self._h, camera_desc, C.byref(options) if options is not None else None,
                   img.ctypes.data_as(C.c_void_p), C.byref(st)))
         return img, st
+
+    def render_u8(self, camera_desc, options: Optional[RtOptions] = None):
+        """Camera::render + Canvas::to_image in one call (rt_render_u8).  Returns (image[rows, W, 3] uint8, RtStats)."""
+        cam = camera_desc.contents if hasattr(camera_desc, "contents") else camera_desc
+        rows = self.output_rows(camera_desc, options)
+        out = np.zeros((rows, cam.hsize, 3), dtype=np.uint8)
+        st = RtStats()
+        _check(lib().rt_render_u8(self._h, camera_desc, C.byref(options) if options is not None else None,
+                                  out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st
+
+    def reserve(self, hsize: int, rows: int) -> None:
+        """rt_scene_reserve: set the scene up for frames of up to hsize x rows (no allocation in later calls)."""
+        _check(lib().rt_scene_reserve(self._h, hsize, rows))
 
     def render_device(self, camera_desc, out_ptr: int, options: Optional[RtOptions] = None, stream: int = 0) -> None:
         """Enqueue Camera::render into DEVICE memory at out_ptr on `stream` (no allocation, no wait)."""

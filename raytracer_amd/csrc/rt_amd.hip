@@ -152,12 +152,44 @@ struct rt_scene {
     uint32_t order_cap = 0;                       // tiles the buffer holds
     uint32_t cost_tiles = 0, cost_tiles_x = 0;    // tiling of the frame whose costs the table holds (0: none yet)
     uint32_t order_flip = 0;
+    // the device image of the host-output entry points (rt_render, rt_render_u8, rt_render_stats): kept between calls
+    float* img = nullptr;
+    size_t img_floats = 0;
+    uint8_t* img8 = nullptr;
+    size_t img8_bytes = 0;
 };
 
 namespace {
 
 // Frames of fewer tiles than the chip holds waves at once (256 CUs x 4 SIMDs x 5) start all their tiles together anyway.
 constexpr uint32_t kOrderMinTiles = 8192;
+
+// The tile-cost table of a scene with glass for frames of up to n_tiles tiles (layout: launch_render below).
+int reserve_order(rt_scene* s, uint32_t n_tiles, hipStream_t stream, bool may_wait) {
+    if (!s->ordered || n_tiles < kOrderMinTiles || n_tiles <= s->order_cap) return RT_OK;
+    if (may_wait) HIP_TRY(hipStreamSynchronize(stream));  // (kernels of earlier calls may still read the old table)
+    if (s->order_buf) (void)hipFree(s->order_buf);
+    s->order_buf = nullptr, s->order_cap = 0, s->cost_tiles = 0;
+    const size_t words = 5u * static_cast<size_t>(n_tiles) + 2u * kOrderClasses;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->order_buf), words * sizeof(uint32_t)));
+    s->order_cap = n_tiles;
+    return RT_OK;
+}
+int reserve_image(rt_scene* s, size_t floats, bool want_u8) {
+    if (floats > s->img_floats) {
+        if (s->img) (void)hipFree(s->img);
+        s->img = nullptr, s->img_floats = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->img), floats * sizeof(float)));
+        s->img_floats = floats;
+    }
+    if (want_u8 && floats > s->img8_bytes) {
+        if (s->img8) (void)hipFree(s->img8);
+        s->img8 = nullptr, s->img8_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->img8), floats));
+        s->img8_bytes = floats;
+    }
+    return RT_OK;
+}
 
 int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt, const RenderPlan& rp, float* d_out,
                   hipStream_t stream, bool stats, unsigned long long* counters = nullptr, uint32_t* tile_rays = nullptr,
@@ -185,13 +217,9 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     if (P.n_tiles == 0) return RT_OK;
     if (s->ordered && allow_order && P.n_tiles >= kOrderMinTiles && !std::getenv("RT_AMD_NO_TILE_ORDER")) {
         // layout of order_buf: [cost: cap][2 x (counters + class words: 32 + cap)][2 x order: cap]
-        if (P.n_tiles > s->order_cap) {  // first call with a frame this large: (re)allocate, then keep
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (s->order_buf) (void)hipFree(s->order_buf);
-            s->order_buf = nullptr, s->order_cap = 0, s->cost_tiles = 0;
-            const size_t words = 5u * static_cast<size_t>(P.n_tiles) + 2u * kOrderClasses;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->order_buf), words * sizeof(uint32_t)));
-            s->order_cap = P.n_tiles;
+        if (P.n_tiles > s->order_cap) {  // first call with a frame this large and no rt_scene_reserve: (re)allocate, then keep
+            const int rc = reserve_order(s, P.n_tiles, stream, true);
+            if (rc != RT_OK) return rc;
         }
         const size_t cap = s->order_cap;
         uint32_t* cost = s->order_buf;
@@ -232,22 +260,24 @@ int launch_render(rt_scene* s, const rt_camera_desc* cam, const rt_options* opt,
     return RT_OK;
 }
 
-int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host,
+int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host, uint8_t* rgb8_out_host,
                 rt_stats* stats_out, bool stats) {
     if (!scene) return fail(RT_ERR_BAD_ARGUMENT, "scene is null");
     RenderPlan rp{};
     int rc = plan_render(camera, options, rp);
     if (rc != RT_OK) return rc;
-    if (!rgb_out_host && !stats) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
+    if (!rgb_out_host && !rgb8_out_host && !stats) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
     if (rp.global_rows) return fail(RT_ERR_BAD_ARGUMENT, "RT_FLAG_GLOBAL_ROWS is for rt_render_device only");
     HIP_TRY(hipSetDevice(scene->device));
     const size_t n = static_cast<size_t>(rp.out_rows) * camera->hsize * 3u;
-    float* d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n ? n * sizeof(float) : sizeof(float)));
+    rc = reserve_image(scene, n ? n : 1u, rgb8_out_host != nullptr);
+    if (rc != RT_OK) return rc;
+    float* const d_out = scene->img;
     hipStream_t stream = nullptr;
     (void)hipEventRecord(scene->ev0, stream);
     rc = launch_render(scene, camera, options, rp, d_out, stream, stats);
     (void)hipEventRecord(scene->ev1, stream);
+    if (rc == RT_OK && rgb8_out_host && n) rc = rt_quantize_u8_device(d_out, n, scene->img8, scene->device, stream);  // canvas.rs:31-45
     if (rc == RT_OK) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
@@ -255,6 +285,10 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
     if (rc == RT_OK && rgb_out_host && n) {
         hipError_t e = hipMemcpy(rgb_out_host, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(D2H)");
+    }
+    if (rc == RT_OK && rgb8_out_host && n) {
+        hipError_t e = hipMemcpy(rgb8_out_host, scene->img8, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(D2H, u8)");
     }
     if (rc == RT_OK && stats_out) {
         std::memset(stats_out, 0, sizeof(*stats_out));
@@ -274,7 +308,6 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
 #endif
         }
     }
-    (void)hipFree(d_out);
     return rc;
 }
 
@@ -363,6 +396,8 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->order_buf) (void)hipFree(s->order_buf);
+    if (s->img) (void)hipFree(s->img);
+    if (s->img8) (void)hipFree(s->img8);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -398,13 +433,31 @@ int rt_render_device(rt_scene* scene, const rt_camera_desc* camera, const rt_opt
 int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host,
               rt_stats* stats_out) {
     if (!rgb_out_host) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
-    return render_host(scene, camera, options, rgb_out_host, stats_out, false);
+    return render_host(scene, camera, options, rgb_out_host, nullptr, stats_out, false);
+}
+
+int rt_render_u8(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, uint8_t* rgb8_out_host,
+                 rt_stats* stats_out) {
+    if (!rgb8_out_host) return fail(RT_ERR_BAD_ARGUMENT, "output buffer is null");
+    return render_host(scene, camera, options, nullptr, rgb8_out_host, stats_out, false);
+}
+
+int rt_scene_reserve(rt_scene* scene, uint32_t hsize, uint32_t rows) {
+    if (!scene) return fail(RT_ERR_BAD_ARGUMENT, "scene is null");
+    if (hsize == 0 || rows == 0) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_reserve: null dimensions");
+    if (static_cast<uint64_t>(hsize) * rows > 0x7FFFFFFFull) return fail(RT_ERR_CAPACITY, "image too large");
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipDeviceSynchronize());  // set-up time: nothing of this scene may be in flight
+    const uint32_t n_tiles = ((hsize + 7u) / 8u) * ((rows + 7u) / 8u);
+    int rc = reserve_order(scene, n_tiles, nullptr, false);
+    if (rc == RT_OK) rc = reserve_image(scene, static_cast<size_t>(hsize) * rows * 3u, true);
+    return rc;
 }
 
 int rt_render_stats(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options, float* rgb_out_host,
                     rt_stats* stats_out) {
     if (!stats_out) return fail(RT_ERR_BAD_ARGUMENT, "stats_out is null");
-    return render_host(scene, camera, options, rgb_out_host, stats_out, true);
+    return render_host(scene, camera, options, rgb_out_host, nullptr, stats_out, true);
 }
 
 int rt_render_stats_noalloc(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,

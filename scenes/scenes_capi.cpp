@@ -65,6 +65,24 @@ int rtx_render_example(const char* name, int width, int height, const rt_options
     }
 }
 
+// `camera.render(&world).to_image()` in one call (Camera::render_image): rgb8 = rows*width*3 bytes.
+int rtx_render_example_u8(const char* name, int width, int height, const rt_options* options, int device, uint8_t* rgb8,
+                          rt_stats* stats) {
+    try {
+        rt::Scene scene;
+        if (!name || !rgb8 || !rt::examples::build(name, static_cast<size_t>(width), static_cast<size_t>(height), scene)) {
+            g_err = std::string("unknown scene: ") + (name ? name : "(null)");
+            return RT_ERR_BAD_ARGUMENT;
+        }
+        const std::vector<uint8_t> bytes = scene.camera.render_image(scene.world, options, device, stats);
+        std::copy(bytes.begin(), bytes.end(), rgb8);
+        return RT_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RT_ERR_BAD_ARGUMENT;
+    }
+}
+
 // `canvas.to_image().save(path)` of examples/*.rs: render, quantise on the device, write a PNG.
 int rtx_render_example_png(const char* name, int width, int height, const rt_options* options, int device, const char* path) {
     try {
@@ -73,9 +91,8 @@ int rtx_render_example_png(const char* name, int width, int height, const rt_opt
             g_err = std::string("unknown scene: ") + (name ? name : "(null)");
             return RT_ERR_BAD_ARGUMENT;
         }
-        const rt::Canvas canvas = scene.camera.render(scene.world, options, device, nullptr);
-        const std::vector<uint8_t> bytes = canvas.to_image();
-        rt::save_png(path, bytes.data(), canvas.width, canvas.height);
+        const std::vector<uint8_t> bytes = scene.camera.render_image(scene.world, options, device, nullptr);
+        rt::save_png(path, bytes.data(), static_cast<size_t>(width), bytes.size() / (static_cast<size_t>(width) * 3));
         return RT_OK;
     } catch (const std::exception& e) {
         g_err = e.what();

@@ -88,6 +88,56 @@ def test_reference_end_to_end_pixel_and_host_api_path():
     assert rc == 0 and np.array_equal(out, img)
 
 
+@pytest.mark.parametrize("name", ["striped_sphere_multiple_lights", "cover_image", "cover_image_area"])
+def test_render_u8_is_render_then_to_image(name):
+    """rt_render_u8 = Camera::render + Canvas::to_image (canvas.rs:31-45) in one call: the same bytes as quantising the
+    float frame of rt_render, for a whole frame, for row bands, and through the host API's Camera::render_image."""
+    w, h = 200, 120
+    ex = ExampleScene(name, w, h)
+    sc = Scene(ex.scene_desc)
+    opt = RtOptions()
+    opt.jitter_mode, opt.seed = 1, 5
+    img, _ = sc.render(ex.camera_desc, opt)
+    want = capi.quantize_u8(img)
+    got, st = sc.render_u8(ex.camera_desc, opt)
+    assert np.array_equal(got, want) and st.kernel_ms > 0
+    img2, _ = sc.render(ex.camera_desc, opt)  # the kept device image serves float and byte calls alike
+    assert np.array_equal(img2, img)
+    band = RtOptions()
+    band.jitter_mode, band.seed, band.tile_rows, band.tile_first, band.tile_stride = 1, 5, 16, 1, 3
+    gb, _ = sc.render_u8(ex.camera_desc, band)
+    rows = capi.band_rows(h, 16, 1, 3)
+    assert gb.shape[0] == len(rows) and np.array_equal(gb, want[rows])
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    rc = scenes_lib().rtx_render_example_u8(name.encode(), w, h, C.byref(opt), 0, out.ctypes.data_as(C.c_void_p), None)
+    assert rc == 0 and np.array_equal(out, want)
+    sc.close()
+
+
+def test_scene_reserve_presizes_what_later_calls_need():
+    """rt_scene_reserve: after it, rt_render_device of a scene whose kernels order their tiles by cost (glass, hierarchy)
+    finds the table in place; the images are those of an unreserved scene, first frame and second."""
+    import torch
+    name, (w, h) = "multiple_glass_and_metallic_spheres", (320, 200)
+    ex = ExampleScene(name, w, h)
+    plain, _ = _render(name, w, h)
+    sc = Scene(ex.scene_desc)
+    sc.reserve(w, h)
+    with pytest.raises(capi.RtError):
+        sc.reserve(0, h)
+    out = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        sc.render_device(ex.camera_desc, out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), plain)
+    big = ExampleScene(name, 2 * w, 2 * h)  # beyond the reserve: still served (the table grows as before)
+    img_big, _ = sc.render(big.camera_desc)
+    ref_big, _ = _render(name, 2 * w, 2 * h)
+    assert np.array_equal(img_big, ref_big)
+    sc.close()
+
+
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_full_resolution_probes(name):
     """256 pixels of the config's FULL-SIZE frame against committed f64 colours."""
