@@ -124,6 +124,7 @@ extern "C" {
     pub fn rt_scene_create(desc: *const rt_scene_desc, device: c_int, scene_out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_variant(scene: *const rt_scene, flags_out: *mut u32) -> c_int;
+    pub fn rt_scene_read_streams(scene: *const rt_scene, out: *mut c_void, cap: usize, bytes_out: *mut usize) -> c_int;
     pub fn rt_output_rows(camera: *const rt_camera_desc, options: *const rt_options, rows_out: *mut u32) -> c_int;
     pub fn rt_render_device(
         scene: *mut rt_scene,

@@ -220,6 +220,12 @@ int rt_scene_reserve(rt_scene* scene, uint32_t hsize, uint32_t rows);
 #define RT_VARIANT_SPAWN 32u   /* some material is reflective or transparent       */
 int rt_scene_variant(const rt_scene* scene, uint32_t* flags_out);
 
+/* The scene's walk streams as the device holds them (tests and tools; no counterpart in the reference): 32-byte
+ * records {float box[6]; uint32 next; uint32 ref}, the canonical order first, then — for a scene with a hierarchy —
+ * the seven other direction orders, which the GPU lays out itself at rt_scene_create.  out may be NULL to ask for the
+ * size; *bytes_out receives it.  RT_ERR_CAPACITY if cap is too small.  Synchronous. */
+int rt_scene_read_streams(const rt_scene* scene, void* out, size_t cap, size_t* bytes_out);
+
 /* Number of output rows a call with these options produces (<= camera vsize). */
 int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint32_t* rows_out);
 

@@ -80,7 +80,7 @@ class RtStats(C.Structure):
 
 # Every symbol include/rt_amd.h declares (tests check that the library exports all of them).
 RT_SYMBOLS = [
-    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_variant",
+    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_variant", "rt_scene_read_streams",
     "rt_output_rows", "rt_render_device", "rt_render", "rt_render_u8", "rt_scene_reserve", "rt_render_stats", "rt_render_stats_noalloc",
     "rt_quantize_u8_device",
     "rt_quantize_u8", "rt_frame_create", "rt_frame_open", "rt_frame_close", "rt_frame_destroy", "rt_frame_download",
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_scene_destroy.restype = None
         L.rt_scene_variant.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rt_scene_read_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_output_rows.argtypes = [C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.POINTER(C.c_uint32)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtOptions), C.c_void_p, C.POINTER(RtStats)]
@@ -210,6 +211,14 @@ class Scene:
         f64 = bool(v.value & 8) and bool(cam.has_f64) and not (options is not None and options.flags & RT_FLAG_F32_ONLY)
         b = lambda x: "true" if x else "false"  # noqa: E731
         return f"render_kernel<{b(stats)}, {b(v.value & 4)}, {b(v.value & 2)}, {b(v.value & 1)}, {b(f64)}, {b(v.value & 16)}, {b(v.value & 32)}>"
+
+    def read_streams(self) -> np.ndarray:
+        """rt_scene_read_streams: the walk streams as the device holds them, [streams * records, 8] uint32 words."""
+        n = C.c_size_t()
+        _check(lib().rt_scene_read_streams(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value // 32, 8), dtype=np.uint32)
+        _check(lib().rt_scene_read_streams(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(n)))
+        return out
 
     def output_rows(self, camera_desc, options: Optional[RtOptions] = None) -> int:
         rows = C.c_uint32()

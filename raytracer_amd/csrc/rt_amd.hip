@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,10 +49,11 @@ int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
-template <class T>
-int upload(const std::vector<T>& v, const T** out, std::vector<void*>& owned) {
+// `copies`: room for that many copies of the table (the first one is filled)
+template <class V, class T = typename V::value_type>
+int upload(const V& v, const T** out, std::vector<void*>& owned, size_t copies = 1) {
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T) * copies));
     owned.push_back(p);
     HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(p);
@@ -335,8 +337,10 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     *scene_out = nullptr;
     PackedScene ps;
     std::string err;
-    int rc = pack_scene(desc, ps, err);
+    const auto t_start = std::chrono::steady_clock::now();
+    int rc = pack_scene(desc, ps, err, /*host_streams=*/false);
     if (rc != RT_OK) return fail(rc, err);
+    const auto t_packed = std::chrono::steady_clock::now();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARGUMENT, "device ordinal out of range");
@@ -349,7 +353,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
     if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
     if (rc == RT_OK) rc = upload(ps.bound, &s->k.bound, s->owned);
-    if (rc == RT_OK) rc = upload(ps.lnodes, &s->k.lnodes, s->owned);
+    if (rc == RT_OK) rc = upload(ps.lnodes, &s->k.lnodes, s->owned, ps.has_bvh ? 8 : 1);
+    if (rc == RT_OK && ps.has_bvh) {  // the other seven direction orders of the hierarchy, laid out by the GPU
+        const uint32_t n = static_cast<uint32_t>(ps.lnodes.size());
+        if (ps.n_top >= n || (ps.lnodes[ps.n_top].ref >> kLRefShift) != REC_NODE) rc = fail(RT_ERR_BAD_ARGUMENT, "internal: the hierarchy has no root record");
+        else {
+            hipLaunchKernelGGL(lane_streams_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, const_cast<LNode*>(s->k.lnodes), n, ps.n_top);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) rc = hip_fail(e, "lane_streams_kernel");
+        }
+    }
     if (rc == RT_OK) rc = upload(ps.gates, &s->k.gates, s->owned);
     if (rc == RT_OK) rc = upload(ps.extras, &s->k.extras, s->owned);
     if (rc == RT_OK) rc = upload(ps.mats, &s->k.mats, s->owned);
@@ -387,6 +401,12 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
         rt_scene_destroy(s);
         return rc;
     }
+    if (std::getenv("RT_AMD_TIMING")) {  // where the time of a large scene goes (scripts/soup_perf.py)
+        const auto t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "rt_scene_create: %u records, host tables %.1f ms (%u threads), device allocations + uploads + stream layout %.1f ms\n", ps.n_items,
+                     std::chrono::duration<double, std::milli>(t_packed - t_start).count(), pack_threads(),
+                     std::chrono::duration<double, std::milli>(t_end - t_packed).count());
+    }
     *scene_out = s;
     return RT_OK;
 }
@@ -407,6 +427,17 @@ int rt_scene_variant(const rt_scene* s, uint32_t* flags_out) {
     if (!s || !flags_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_variant: null argument");
     *flags_out = (s->area ? RT_VARIANT_AREA : 0u) | (s->tree ? RT_VARIANT_TREE : 0u) | (s->exotic ? RT_VARIANT_EXOTIC : 0u) |
                  (s->has_f64 ? RT_VARIANT_F64 : 0u) | (s->lane ? RT_VARIANT_LANE : 0u) | ((s->spawn || (s->lane && s->tree)) ? RT_VARIANT_SPAWN : 0u);
+    return RT_OK;
+}
+
+int rt_scene_read_streams(const rt_scene* s, void* out, size_t cap, size_t* bytes_out) {
+    if (!s || !bytes_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_read_streams: null argument");
+    const size_t bytes = static_cast<size_t>(s->k.has_bvh ? 8u : 1u) * std::max<uint32_t>(s->k.n_items, 1u) * sizeof(LNode);
+    *bytes_out = bytes;
+    if (!out) return RT_OK;
+    if (cap < bytes) return fail(RT_ERR_CAPACITY, "rt_scene_read_streams: the buffer is too small");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(out, s->k.lnodes, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

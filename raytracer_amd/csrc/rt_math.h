@@ -70,10 +70,13 @@ struct DPrim {  // 64 B — one s_load_dwordx16 when the index is wave-uniform
 struct alignas(32) LNode {
     float inv[6];   // box min = inv[0..2], max = inv[3..5] (the field names of DPrim: the box tests take either)
     uint32_t next;  // node: the position after its subtree IN THIS STREAM.  primitive: its position + 1
-    uint32_t ref;   // primitive: type << kLRefShift | record index in the canonical stream.  node: REC_NODE << kLRefShift
+    uint32_t ref;   // primitive: type << kLRefShift | record index in the canonical stream.  node: REC_NODE << kLRefShift | split axis
 };
 constexpr uint32_t kLRefShift = 29u;
 constexpr uint32_t kLRefMask = (1u << kLRefShift) - 1u;
+// (a node's low bits: the axis it was split along, 0..2, or kLeafAxis for a node over two primitives, whose order is the
+// same in every stream.  The walks never look at them; the kernel that lays the direction-ordered streams out does.)
+constexpr uint32_t kLeafAxis = 3u;
 struct DExtra {  // 128 B: cylinder {min,max,closed}; triangle {v0,e0,e1,normal,n0,n1,n2}
     float f[32];
 };

@@ -17,8 +17,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -27,21 +33,44 @@
 
 namespace rtk {
 
+// The per-record tables of a large scene are hundreds of megabytes that pack_scene's threads fill record by record:
+// a vector that does not zero them first (resize() leaves trivially constructible elements as they are).
+template <class T>
+struct LeaveAlone : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = LeaveAlone<U>;
+    };
+    template <class U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <class T>
+using PodVec = std::vector<T, LeaveAlone<T>>;
+
 struct PackedScene {
-    std::vector<DPrim> recs;      // the traversal stream
-    std::vector<uint32_t> order;  // per record: the primitive's position in world.objects order (nodes: 0)
-    std::vector<uint32_t> gate;   // per record: innermost enclosing Group (index into gates) or kNoGate
-    std::vector<DBound> bound;    // per record: world-space bounding ball (shaft tests)
-    std::vector<LNode> lnodes;    // per record: the compact twin of the stream (lane-mode walks)
+    PodVec<DPrim> recs;       // the traversal stream
+    PodVec<uint32_t> order;   // per record: the primitive's position in world.objects order (nodes: 0)
+    PodVec<uint32_t> gate;    // per record: innermost enclosing Group (index into gates) or kNoGate
+    PodVec<DBound> bound;     // per record: world-space bounding ball (shaft tests)
+    // per record: the compact twin of the stream (lane-mode walks): the canonical order, then — only if the caller of
+    // pack_scene asked for them (host_streams) — the seven other direction orders; rt_scene_create makes those on the GPU
+    PodVec<LNode> lnodes;
+    uint32_t n_top = 0;           // records in front of the hierarchy's root (unbounded primitives)
     std::vector<DGate> gates;     // the caller's Groups
-    std::vector<DExtra> extras;
+    PodVec<DExtra> extras;
     std::vector<DMaterial> mats;
     std::vector<DPattern> pats;
     std::vector<DLight> lights;
     // the caller's f64 tables for the exact chain (rt_exact.h), laid out like their FP32 twins: per stream
     // record, per DExtra slot, per material, per pattern.  Empty when the caller did not provide them.
-    std::vector<XPrim> xprims;
-    std::vector<XExtra> xextras;
+    PodVec<XPrim> xprims;
+    PodVec<XExtra> xextras;
     std::vector<double> xior;
     std::vector<XPattern> xpats;
     std::vector<XLight> xlights;  // always filled: the caller's f64 light geometry, or the f32 values widened
@@ -228,175 +257,344 @@ inline DBound node_ball(const DPrim& node) {
     return b;
 }
 
+// ---- worker threads of rt_scene_create -------------------------------------------------------------------------------
+// RT_AMD_THREADS, else OMP_NUM_THREADS (the GPU boxes set it to their CPU share), else the machine's count; at most 32.
+inline unsigned pack_threads() {
+    static const unsigned n = [] {
+        long v = 0;
+        for (const char* name : {"RT_AMD_THREADS", "OMP_NUM_THREADS"}) {
+            const char* e = std::getenv(name);
+            if (e && *e && (v = std::strtol(e, nullptr, 10)) > 0) break;
+            v = 0;
+        }
+        if (v <= 0) v = static_cast<long>(std::thread::hardware_concurrency());
+        return static_cast<unsigned>(v < 1 ? 1 : (v > 32 ? 32 : v));
+    }();
+    return n;
+}
+// fn(chunk, lo, hi) over [0, n) cut into at most pack_threads() contiguous chunks of at least `grain` elements; returns the
+// number of chunks.  The chunk boundaries depend on n and the thread count only; every user below is written so that
+// its RESULT does not depend on them (min/max merges, stable scatters, disjoint stores).
+template <class F>
+inline unsigned parallel_chunks(size_t n, size_t grain, F&& fn) {
+    size_t chunks = std::min<size_t>(pack_threads(), grain ? (n + grain - 1) / grain : 1);
+    if (chunks <= 1) {
+        if (n) fn(0u, size_t{0}, n);
+        return n ? 1u : 0u;
+    }
+    std::vector<std::thread> th;
+    th.reserve(chunks - 1);
+    for (size_t c = 1; c < chunks; ++c) th.emplace_back([&fn, c, n, chunks] { fn(static_cast<unsigned>(c), c * n / chunks, (c + 1) * n / chunks); });
+    fn(0u, size_t{0}, n / chunks);
+    for (auto& t : th) t.join();
+    return static_cast<unsigned>(chunks);
+}
+
+// The 64-byte record of one of the caller's primitives, made where it is needed (no intermediate copies of a million of
+// them): `extra_of[i]` = the DExtra slot of primitive i (cylinders and triangles).
+struct PrimSource {
+    const rt_scene_desc* d = nullptr;
+    const uint32_t* extra_of = nullptr;
+    const DMaterial* mats = nullptr;
+    DPrim record(uint32_t i) const {
+        DPrim p{};
+        std::memcpy(p.inv, d->prim_inv + 12 * static_cast<size_t>(i), sizeof(p.inv));
+        p.type = d->prim_type[i];
+        p.material = d->prim_material[i];
+        p.ior = mats[p.material].ior;
+        p.extra = p.type >= RT_PRIM_CYLINDER ? extra_of[i] : 0u;
+        return p;
+    }
+};
+
 // The device's own hierarchy over the bounded primitives: a binary tree built top-down with the surface-area
 // heuristic (16 bins per axis over the centroids; expected cost of a split = area(left) * n(left) + area(right) *
 // n(right); the median along the widest axis when the bins cannot separate anything), at most two primitives
-// per leaf.  It is emitted once in canonical order (low side of every split first) into the record stream, and
-// eight times — one per sign pattern of a ray direction — into the compact LNode streams (rt_math.h).
+// per leaf (it stands in for Group::divide, group.rs:168-231, which the reference runs once per scene on one thread).
+//
+// A subtree over n primitives takes exactly 2n - 1 records (a bare record for a single primitive, a box record + two
+// primitives for a pair, 1 + left + right above that), so the place of every record in the canonical stream (pre-order,
+// low side of every split first) AND in the seven other direction-ordered streams (far child first where the ray's
+// direction is negative along the split axis) is known on the way DOWN.  The build therefore has no tree to keep and no
+// emission pass: each subtree writes its records where they belong, subtrees are independent, and a pool of host threads
+// takes them from a shared stack (big nodes also bin and partition their range with all threads).  The result does not
+// depend on the number of threads or on who built what.
 struct BvhBuild {
-    struct TNode {
-        HostBox box;
-        int left = -1, right = -1;  // subtrees (indices into `tree`), or -1
-        int axis = 0;               // split axis (inner nodes)
-        uint32_t lo = 0, hi = 0;    // leaf: perm[lo, hi) (1 or 2 primitives); a single primitive has no box record
-        uint32_t rec = 0;           // position of the node's record in the canonical stream (boxed nodes)
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kSpawn = 4096;     // subtrees above this many primitives are handed to the pool
+    static constexpr uint32_t kWide = 1u << 17;  // nodes above this many primitives use all threads for their own passes
+    // A primitive as the build moves it around: its box travels with it, so every pass over a range reads memory in
+    // order (a permutation of indices into a box table made the build wait on a cache miss per primitive per level).
+    struct Item {
+        double mn[3], mx[3];
+        uint32_t k;  // index into `ids`: the primitive's rank in world.objects order among the bounded ones
     };
-    std::vector<HostBox> boxes;  // per bounded primitive (index into `ids`)
-    std::vector<uint32_t> ids;   // item index of each bounded primitive
-    std::vector<uint32_t> perm;  // working permutation
-    std::vector<TNode> tree;
-    std::vector<uint32_t> prim_rec;  // per bounded primitive k: its position in the canonical stream
+    struct Task {
+        uint32_t lo, hi;  // items [lo, hi) ...
+        uint32_t side;    // ... of buf[side]
+        int depth;
+        uint32_t pos[8];  // first record of the subtree in each stream
+    };
+    PodVec<Item> buf[2];        // the partitions scatter a range from one into the same range of the other
+    std::vector<uint32_t> ids;  // item index of each bounded primitive
     PackedScene* out = nullptr;
-    const std::vector<DPrim>* item_rec = nullptr;  // record of each item (primitives only)
+    const PrimSource* src = nullptr;
     const std::vector<uint32_t>* item_gate = nullptr;
+    uint32_t n_streams = 1;  // 1: canonical stream only; 8: + the direction-ordered ones
+    size_t total = 0;        // records per stream
+
+    // the pool
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Task> stack;
+    size_t open_tasks = 0;  // queued or running
 
     static double area(const HostBox& b) {
         const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
         return (dx < 0 || dy < 0 || dz < 0) ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
     }
-    int build(uint32_t lo, uint32_t hi, int depth = 0) {  // perm[lo, hi) -> index into `tree`
-        const uint32_t n = hi - lo;
-        TNode node;
-        node.box = HostBox::empty();
-        HostBox cen = HostBox::empty();
-        for (uint32_t k = lo; k < hi; ++k) {
-            const HostBox& b = boxes[perm[k]];
-            node.box.merge(b);
-            double c[3] = {0.5 * (b.mn[0] + b.mx[0]), 0.5 * (b.mn[1] + b.mx[1]), 0.5 * (b.mn[2] + b.mx[2])};
-            cen.add(c);
+    static void merge(HostBox& into, const Item& it) {
+        for (int k = 0; k < 3; ++k) into.mn[k] = std::min(into.mn[k], it.mn[k]), into.mx[k] = std::max(into.mx[k], it.mx[k]);
+    }
+    static LNode prim_lnode(bool bounded, const double* mn, const double* mx, uint32_t type, uint32_t rec, uint32_t next) {
+        LNode ln{};
+        for (int k = 0; k < 3; ++k) {
+            ln.inv[k] = bounded ? widen(std::nextafter(static_cast<float>(mn[k]), -INFINITY), false) : -INFINITY;
+            ln.inv[3 + k] = bounded ? widen(std::nextafter(static_cast<float>(mx[k]), INFINITY), true) : INFINITY;
         }
-        node.lo = lo, node.hi = hi;
-        if (n <= 2) {
-            tree.push_back(node);
-            return static_cast<int>(tree.size()) - 1;
+        ln.next = next;
+        ln.ref = (type << kLRefShift) | rec;
+        return ln;
+    }
+    void put_prim(const Item& it, const uint32_t* pos) {
+        const uint32_t item = ids[it.k], at = pos[0];
+        const DPrim r = src->record(src->d->item_ref[item]);
+        out->recs[at] = r, out->order[at] = item, out->gate[at] = (*item_gate)[item];
+        for (uint32_t o = 0; o < n_streams; ++o) out->lnodes[o * total + pos[o]] = prim_lnode(true, it.mn, it.mx, r.type, at, pos[o] + 1u);
+    }
+    // axis: the split axis, or kLeafAxis for a pair of primitives (whose order no direction changes)
+    void put_node(const HostBox& box, uint32_t n, uint32_t axis, const uint32_t* pos) {
+        DPrim node{};
+        for (int k = 0; k < 3; ++k) {
+            node.inv[k] = widen(std::nextafter(static_cast<float>(box.mn[k]), -INFINITY), false);
+            node.inv[3 + k] = widen(std::nextafter(static_cast<float>(box.mx[k]), INFINITY), true);
         }
-        constexpr int kBins = 16;
+        node.type = REC_NODE;
+        node.material = pos[0] + 2u * n - 1u;  // skip link
+        out->recs[pos[0]] = node, out->order[pos[0]] = 0, out->gate[pos[0]] = kNoGate;
+        LNode ln{};
+        for (int k = 0; k < 6; ++k) ln.inv[k] = node.inv[k];
+        ln.ref = (REC_NODE << kLRefShift) | axis;
+        for (uint32_t o = 0; o < n_streams; ++o) {
+            ln.next = pos[o] + 2u * n - 1u;
+            out->lnodes[o * total + pos[o]] = ln;
+        }
+    }
+    struct Bins {
+        HostBox box[3][kBins];
+        uint32_t n[3][kBins];
+        Bins() {
+            for (auto& a : box)
+                for (auto& b : a) b = HostBox::empty();
+            std::memset(n, 0, sizeof(n));
+        }
+    };
+    static int bin_of(const Item& b, int axis, double c0, double ext) {
+        const int bi = static_cast<int>((0.5 * (b.mn[axis] + b.mx[axis]) - c0) / ext * kBins);
+        return bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+    }
+    // One subtree: writes its records, hands big children to the pool (push), descends into the rest itself.
+    template <class Push>
+    void subtree(Task t, Push&& push) {
+        const uint32_t lo = t.lo, hi = t.hi, n = hi - lo;
+        Item* items = buf[t.side].data();
+        if (n == 1) {
+            put_prim(items[lo], t.pos);
+            return;
+        }
+        const size_t grain = n > kWide ? size_t{1} << 15 : size_t{n};  // (the top few nodes: the pool has little else to do yet)
+        // the node's box and the box of the centroids
+        HostBox box = HostBox::empty(), cen = HostBox::empty();
+        {
+            HostBox pb[32], pc[32];
+            const unsigned chunks = parallel_chunks(n, grain, [&](unsigned c, size_t a, size_t e) {
+                HostBox b0 = HostBox::empty(), c0 = HostBox::empty();
+                for (size_t k = lo + a; k < lo + e; ++k) {
+                    const Item& b = items[k];
+                    merge(b0, b);
+                    const double ctr[3] = {0.5 * (b.mn[0] + b.mx[0]), 0.5 * (b.mn[1] + b.mx[1]), 0.5 * (b.mn[2] + b.mx[2])};
+                    c0.add(ctr);
+                }
+                pb[c] = b0, pc[c] = c0;
+            });
+            for (unsigned c = 0; c < chunks; ++c) box.merge(pb[c]), cen.merge(pc[c]);
+        }
+        if (n == 2) {
+            put_node(box, n, kLeafAxis, t.pos);
+            uint32_t p1[8], p2[8];
+            for (uint32_t o = 0; o < n_streams; ++o) p1[o] = t.pos[o] + 1u, p2[o] = t.pos[o] + 2u;
+            put_prim(items[lo], p1), put_prim(items[lo + 1], p2);
+            return;
+        }
+        // the bins of the three axes in one pass
+        double c0[3], ext[3];
+        bool use[3];
+        for (int axis = 0; axis < 3; ++axis) {
+            c0[axis] = cen.mn[axis], ext[axis] = cen.mx[axis] - cen.mn[axis];
+            use[axis] = ext[axis] > 0.0 && std::isfinite(ext[axis]);
+        }
+        Bins bins;
+        auto fill = [&](Bins& w, size_t a, size_t e) {
+            for (size_t k = lo + a; k < lo + e; ++k) {
+                const Item& b = items[k];
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (!use[axis]) continue;
+                    const int bi = bin_of(b, axis, c0[axis], ext[axis]);
+                    merge(w.box[axis][bi], b), w.n[axis][bi]++;
+                }
+            }
+        };
+        if (grain >= n) {
+            fill(bins, 0, n);
+        } else {
+            std::vector<Bins> part(pack_threads());
+            const unsigned chunks = parallel_chunks(n, grain, [&](unsigned c, size_t a, size_t e) { fill(part[c], a, e); });
+            for (unsigned c = 0; c < chunks; ++c)
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int i = 0; i < kBins; ++i)
+                        if (part[c].n[axis][i]) bins.box[axis][i].merge(part[c].box[axis][i]), bins.n[axis][i] += part[c].n[axis][i];
+        }
         int best_axis = -1, best_bin = 0;
         double best_cost = INFINITY;
         for (int axis = 0; axis < 3; ++axis) {
-            const double c0 = cen.mn[axis], ext = cen.mx[axis] - cen.mn[axis];
-            if (!(ext > 0.0) || !std::isfinite(ext)) continue;
-            HostBox bin_box[kBins];
-            uint32_t bin_n[kBins] = {0};
-            for (auto& b : bin_box) b = HostBox::empty();
-            for (uint32_t k = lo; k < hi; ++k) {
-                const HostBox& b = boxes[perm[k]];
-                int bi = static_cast<int>((0.5 * (b.mn[axis] + b.mx[axis]) - c0) / ext * kBins);
-                bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
-                bin_box[bi].merge(b), bin_n[bi]++;
-            }
+            if (!use[axis]) continue;
             double right_area[kBins];
             uint32_t right_n[kBins];
             HostBox acc = HostBox::empty();
             uint32_t cnt = 0;
+            double a_acc = area(acc);  // (an empty bin changes neither the box nor its area)
             for (int i = kBins - 1; i > 0; --i) {
-                if (bin_n[i]) acc.merge(bin_box[i]);
-                cnt += bin_n[i];
-                right_area[i] = area(acc), right_n[i] = cnt;
+                if (bins.n[axis][i]) acc.merge(bins.box[axis][i]), a_acc = area(acc);
+                cnt += bins.n[axis][i];
+                right_area[i] = a_acc, right_n[i] = cnt;
             }
-            acc = HostBox::empty(), cnt = 0;
+            acc = HostBox::empty(), cnt = 0, a_acc = area(acc);
             for (int i = 0; i + 1 < kBins; ++i) {  // split between bin i and bin i + 1
-                if (bin_n[i]) acc.merge(bin_box[i]);
-                cnt += bin_n[i];
+                if (bins.n[axis][i]) acc.merge(bins.box[axis][i]), a_acc = area(acc);
+                cnt += bins.n[axis][i];
                 if (cnt == 0 || right_n[i + 1] == 0) continue;
-                const double cost = area(acc) * cnt + right_area[i + 1] * right_n[i + 1];
+                const double cost = a_acc * cnt + right_area[i + 1] * right_n[i + 1];
                 if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = i;
             }
         }
-        uint32_t mid = lo + n / 2;
-        if (best_axis >= 0 && depth < 40) {  // (deeper than that the splits are lopsided: halve instead)
-            const int axis = best_axis;
-            const double c0 = cen.mn[axis], ext = cen.mx[axis] - cen.mn[axis];
-            auto bin_of = [&](uint32_t a) {
-                int bi = static_cast<int>((0.5 * (boxes[a].mn[axis] + boxes[a].mx[axis]) - c0) / ext * kBins);
-                return bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
-            };
-            auto it = std::stable_partition(perm.begin() + lo, perm.begin() + hi, [&](uint32_t a) { return bin_of(a) <= best_bin; });
-            mid = static_cast<uint32_t>(it - perm.begin());
-            node.axis = axis;
-        }
-        if (best_axis < 0 || depth >= 40 || mid == lo || mid == hi) {  // nothing to separate by: the median along the widest axis
-            int axis = 0;
-            double ext = -1.0;
-            for (int k = 0; k < 3; ++k)
-                if (cen.mx[k] - cen.mn[k] > ext) ext = cen.mx[k] - cen.mn[k], axis = k;
-            mid = lo + n / 2;
-            std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, [&](uint32_t a, uint32_t b) {
-                const double ca = boxes[a].mn[axis] + boxes[a].mx[axis], cb = boxes[b].mn[axis] + boxes[b].mx[axis];
-                return ca < cb || (ca == cb && a < b);
+        uint32_t mid = lo + n / 2, side = t.side;
+        int axis = 0;
+        if (best_axis >= 0 && t.depth < 40) {  // (deeper than that the splits are lopsided: halve instead)
+            axis = best_axis;
+            // stable partition by scattering into the other buffer: each side keeps its order
+            uint32_t n_low[32];
+            auto low = [&](const Item& a) { return bin_of(a, axis, c0[axis], ext[axis]) <= best_bin; };
+            const unsigned chunks = parallel_chunks(n, grain, [&](unsigned c, size_t a, size_t e) {
+                uint32_t m = 0;
+                for (size_t k = lo + a; k < lo + e; ++k) m += low(items[k]) ? 1u : 0u;
+                n_low[c] = m;
             });
-            node.axis = axis;
-        }
-        const int l = build(lo, mid, depth + 1);
-        const int r = build(mid, hi, depth + 1);
-        node.left = l, node.right = r;
-        tree.push_back(node);
-        return static_cast<int>(tree.size()) - 1;
-    }
-    void emit_prim(uint32_t k) {
-        const uint32_t item = ids[k];
-        prim_rec[k] = static_cast<uint32_t>(out->recs.size());
-        out->recs.push_back((*item_rec)[item]);
-        out->order.push_back(item);
-        out->gate.push_back((*item_gate)[item]);
-    }
-    // canonical stream: pre-order, low side first
-    void emit(int t) {
-        TNode& nd = tree[t];
-        if (nd.left < 0 && nd.hi - nd.lo == 1) {
-            emit_prim(perm[nd.lo]);
-            return;
-        }
-        const size_t at = out->recs.size();
-        nd.rec = static_cast<uint32_t>(at);
-        DPrim node{};
-        for (int k = 0; k < 3; ++k) {
-            node.inv[k] = widen(std::nextafter(static_cast<float>(nd.box.mn[k]), -INFINITY), false);
-            node.inv[3 + k] = widen(std::nextafter(static_cast<float>(nd.box.mx[k]), INFINITY), true);
-        }
-        node.type = REC_NODE;
-        out->recs.push_back(node);
-        out->order.push_back(0);
-        out->gate.push_back(kNoGate);
-        if (nd.left < 0) {
-            for (uint32_t k = nd.lo; k < nd.hi; ++k) emit_prim(perm[k]);
-        } else {
-            emit(nd.left);
-            emit(nd.right);
-        }
-        out->recs[at].material = static_cast<uint32_t>(out->recs.size());  // skip link
-    }
-    // the compact stream of one direction octant (bit k of `oct` set: the ray's direction is negative along axis k)
-    void emit_lane(int t, uint32_t oct, std::vector<LNode>& dst, const std::vector<LNode>& prim_node) const {
-        const TNode& nd = tree[t];
-        if (nd.left < 0 && nd.hi - nd.lo == 1) {
-            LNode ln = prim_node[prim_rec[perm[nd.lo]]];
-            ln.next = static_cast<uint32_t>(dst.size()) + 1u;
-            dst.push_back(ln);
-            return;
-        }
-        const size_t at = dst.size();
-        LNode ln{};
-        for (int k = 0; k < 6; ++k) ln.inv[k] = out->recs[nd.rec].inv[k];
-        ln.ref = REC_NODE << kLRefShift;
-        dst.push_back(ln);
-        if (nd.left < 0) {
-            for (uint32_t k = nd.lo; k < nd.hi; ++k) {
-                LNode pl = prim_node[prim_rec[perm[k]]];
-                pl.next = static_cast<uint32_t>(dst.size()) + 1u;
-                dst.push_back(pl);
+            uint32_t all_low = 0;
+            for (unsigned c = 0; c < chunks; ++c) all_low += n_low[c];
+            mid = lo + all_low;
+            if (mid != lo && mid != hi) {
+                Item* dst = buf[side ^ 1u].data();
+                parallel_chunks(n, grain, [&](unsigned c, size_t a, size_t e) {
+                    uint32_t l = lo, h = mid + static_cast<uint32_t>(a);
+                    for (unsigned q = 0; q < c; ++q) l += n_low[q];
+                    h -= l - lo;  // the high elements in front of this chunk
+                    for (size_t k = lo + a; k < lo + e; ++k) {
+                        if (low(items[k])) dst[l++] = items[k];
+                        else dst[h++] = items[k];
+                    }
+                });
+                side ^= 1u;
             }
-        } else {
-            const bool flip = ((oct >> nd.axis) & 1u) != 0;
-            emit_lane(flip ? nd.right : nd.left, oct, dst, prim_node);
-            emit_lane(flip ? nd.left : nd.right, oct, dst, prim_node);
         }
-        dst[at].next = static_cast<uint32_t>(dst.size());
+        if (best_axis < 0 || t.depth >= 40 || mid == lo || mid == hi) {  // nothing to separate by: the median along the widest axis
+            axis = 0;
+            double widest = -1.0;
+            for (int k = 0; k < 3; ++k)
+                if (cen.mx[k] - cen.mn[k] > widest) widest = cen.mx[k] - cen.mn[k], axis = k;
+            mid = lo + n / 2;
+            std::nth_element(items + lo, items + mid, items + hi, [&](const Item& a, const Item& b) {
+                const double ca = a.mn[axis] + a.mx[axis], cb = b.mn[axis] + b.mx[axis];
+                return ca < cb || (ca == cb && a.k < b.k);
+            });
+        }
+        put_node(box, n, static_cast<uint32_t>(axis), t.pos);
+        const uint32_t nl = mid - lo, nr = hi - mid;
+        Task l{lo, mid, side, t.depth + 1, {}}, r{mid, hi, side, t.depth + 1, {}};
+        for (uint32_t o = 0; o < n_streams; ++o) {
+            const bool flip = ((o >> axis) & 1u) != 0;  // bit k of o set: the ray's direction is negative along axis k
+            l.pos[o] = t.pos[o] + 1u + (flip ? 2u * nr - 1u : 0u);
+            r.pos[o] = t.pos[o] + 1u + (flip ? 0u : 2u * nl - 1u);
+        }
+        if (n > kSpawn) {
+            push(r);
+            push(l);
+            return;
+        }
+        subtree(l, push);
+        subtree(r, push);
+    }
+    // Builds the tree over buf[0][0, n) with its first record at `first` of every stream.
+    void run(uint32_t first) {
+        Task root{0, static_cast<uint32_t>(buf[0].size()), 0u, 0, {}};
+        for (uint32_t& p : root.pos) p = first;
+        buf[1].resize(buf[0].size());
+        stack.push_back(root);
+        open_tasks = 1;
+        auto worker = [this] {
+            auto push = [this](const Task& t) {
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    stack.push_back(t);
+                    ++open_tasks;
+                }
+                cv.notify_one();
+            };
+            for (;;) {
+                Task t;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [this] { return !stack.empty() || open_tasks == 0; });
+                    if (stack.empty()) return;
+                    t = stack.back();
+                    stack.pop_back();
+                }
+                subtree(t, push);
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    --open_tasks;
+                }
+                cv.notify_all();
+            }
+        };
+        const unsigned n_threads = buf[0].size() > kSpawn ? pack_threads() : 1u;
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < n_threads; ++i) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
     }
 };
 
+#ifdef RT_PACK_TIMING  // (scratch/pack_time.cpp: where the time of a large scene goes)
+#include <chrono>
+inline double g_pack_marks[16];
+#define RT_PACK_MARK(i) g_pack_marks[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()
+#else
+#define RT_PACK_MARK(i) ((void)0)
+#endif
 // Returns RT_OK or a negative rt_status; `err` receives the message.
-inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err) {
+// host_streams: lay the seven other direction-ordered LNode streams out here as well (the host simulator of the tests);
+// rt_scene_create makes them on the GPU from the canonical one (lane_streams_kernel, rt_aux_kernels.h).
+inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err, bool host_streams = true) {
     auto bad = [&](const char* m) {
         err = m;
         return static_cast<int>(RT_ERR_BAD_ARGUMENT);
@@ -420,6 +618,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         return RT_ERR_CAPACITY;
     }
 
+    RT_PACK_MARK(0);
     out = PackedScene{};
     const int n64 = (d->prim_inv64 ? 1 : 0) + (d->prim_param64 ? 1 : 0) + (d->mat_ior64 ? 1 : 0) + (d->pat_inv64 ? 1 : 0);
     if (n64 != 0 && n64 != 4) return bad("the f64 tables (prim_inv64, prim_param64, mat_ior64, pat_inv64) come all four or not at all");
@@ -449,39 +648,41 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         out.any_glass |= !(std::fabs(m[6]) <= kEps);
         if (out.has_f64) out.xior.push_back(d->mat_ior64[i]);
     }
-    std::vector<DPrim> prims;  // by primitive index
+    RT_PACK_MARK(1);
+    // by primitive index: validation and the DExtra slots (a running count), then the slots filled by all threads
+    std::vector<uint32_t> extra_of(d->n_prims, 0u);
+    uint32_t n_extras = 0;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         if (d->prim_type[i] > RT_PRIM_SMOOTH_TRIANGLE) {
             err = "unknown primitive tag";
             return RT_ERR_UNSUPPORTED;
         }
         if (d->prim_material[i] >= d->n_materials) return bad("primitive material index out of range");
-        DPrim p{};
-        std::memcpy(p.inv, d->prim_inv + 12 * i, sizeof(p.inv));
-        p.type = d->prim_type[i];
-        p.material = d->prim_material[i];
-        p.ior = out.mats[p.material].ior;
-        p.extra = 0;
-        if (p.type >= RT_PRIM_CYLINDER) {
-            if (!d->prim_param) return bad("prim_param is null but a cylinder/triangle needs it");
+        if (d->prim_type[i] >= RT_PRIM_CYLINDER) extra_of[i] = n_extras++;
+    }
+    if (n_extras && !d->prim_param) return bad("prim_param is null but a cylinder/triangle needs it");
+    out.extras.resize(n_extras);
+    if (out.has_f64) out.xextras.resize(n_extras);
+    parallel_chunks(n_extras ? d->n_prims : 0, 1u << 14, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            if (d->prim_type[i] < RT_PRIM_CYLINDER) continue;
             DExtra e{};
             std::memcpy(e.f, d->prim_param + 24 * i, 24 * sizeof(float));
-            p.extra = static_cast<uint32_t>(out.extras.size());
-            out.extras.push_back(e);
+            out.extras[extra_of[i]] = e;
             if (out.has_f64) {
                 XExtra xe{};
                 std::memcpy(xe.f, d->prim_param64 + 24 * i, sizeof(xe.f));
-                out.xextras.push_back(xe);
+                out.xextras[extra_of[i]] = xe;
             }
         }
-        prims.push_back(p);
-    }
+    });
+    const PrimSource src{d, extra_of.data(), out.mats.data()};
     if (out.extras.empty()) out.extras.push_back(DExtra{});  // never hand a null table to the kernel
     if (out.xextras.empty()) out.xextras.push_back(XExtra{});
 
+    RT_PACK_MARK(2);
     // The caller's item tree: pre-order with forward skip links.  i < next <= n_items and proper
     // nesting are checked; Groups become gates, primitives remember their innermost Group.
-    std::vector<DPrim> item_rec(d->n_items);
     std::vector<uint32_t> item_gate(d->n_items, kNoGate);
     std::vector<uint32_t> prim_items;  // items that are primitives, in world.objects order
     {
@@ -514,93 +715,95 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
                 if (next != i + 1) return bad("a primitive item must link to the next item");
                 if (prim_seen[ref]) return bad("primitive referenced by more than one item");
                 prim_seen[ref] = 1;
-                item_rec[i] = prims[ref];
                 item_gate[i] = enclosing;
                 prim_items.push_back(i);
-                out.exotic |= prims[ref].type >= PRIM_CYLINDER;
+                out.exotic |= d->prim_type[ref] >= RT_PRIM_CYLINDER;
                 out.has_gates |= enclosing != kNoGate;
             }
         }
     }
     if (out.gates.empty()) out.gates.push_back(DGate{});
 
-    // Lay the stream out.
-    auto emit_flat = [&](uint32_t item) {
-        out.recs.push_back(item_rec[item]);
-        out.order.push_back(item);
-        out.gate.push_back(item_gate[item]);
-    };
+    RT_PACK_MARK(3);
+    // Lay the stream out: unbounded primitives (and everything, in a flat scene) in front, in world.objects order, then the
+    // hierarchy over the bounded ones.
     BvhBuild b;
-    int root = -1;
-    uint32_t n_top = 0;
-    if (prim_items.size() <= kFlatLimit && !out.has_gates) {
-        for (uint32_t item : prim_items) emit_flat(item);
-    } else {
-        b.out = &out, b.item_rec = &item_rec, b.item_gate = &item_gate;
-        for (uint32_t item : prim_items) {
-            const uint32_t ref = d->item_ref[item];
-            const HostBox box = prim_world_box(d->prim_type[ref], d->prim_inv + 12 * ref,
-                                               d->prim_param ? d->prim_param + 24 * ref : nullptr);
-            if (box.bounded) b.boxes.push_back(box), b.ids.push_back(item);
-            else emit_flat(item);  // unbounded primitives stay at the top, in order
-        }
-        if (b.ids.size() <= 2) {
-            for (uint32_t item : b.ids) emit_flat(item);
+    std::vector<uint32_t> front;  // items in front of the tree
+    {
+        const bool flat = prim_items.size() <= kFlatLimit && !out.has_gates;
+        std::vector<HostBox> box(flat ? 0 : prim_items.size());
+        parallel_chunks(box.size(), 1u << 14, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) {
+                const uint32_t ref = d->item_ref[prim_items[k]];
+                box[k] = prim_world_box(d->prim_type[ref], d->prim_inv + 12 * ref, d->prim_param ? d->prim_param + 24 * ref : nullptr);
+            }
+        });
+        size_t n_bounded = 0;
+        for (const HostBox& x : box) n_bounded += x.bounded ? 1 : 0;
+        if (flat || n_bounded <= 2) {
+            front = prim_items;
         } else {
-            b.perm.resize(b.ids.size());
-            b.prim_rec.assign(b.ids.size(), 0u);
-            for (uint32_t k = 0; k < b.perm.size(); ++k) b.perm[k] = k;
-            root = b.build(0, static_cast<uint32_t>(b.perm.size()));
-            n_top = static_cast<uint32_t>(out.recs.size());  // the unbounded primitives in front of the tree
-            b.emit(root);
+            b.buf[0].reserve(n_bounded), b.ids.reserve(n_bounded);
+            for (size_t k = 0; k < box.size(); ++k) {
+                if (!box[k].bounded) {
+                    front.push_back(prim_items[k]);
+                    continue;
+                }
+                BvhBuild::Item it;
+                for (int c = 0; c < 3; ++c) it.mn[c] = box[k].mn[c], it.mx[c] = box[k].mx[c];
+                it.k = static_cast<uint32_t>(b.ids.size());
+                b.buf[0].push_back(it), b.ids.push_back(prim_items[k]);
+            }
             out.has_bvh = true;
         }
     }
-    out.n_items = static_cast<uint32_t>(out.recs.size());
-    if (out.recs.empty()) out.recs.push_back(DPrim{}), out.order.push_back(0), out.gate.push_back(kNoGate);
-    for (const DPrim& r : out.recs)
-        out.bound.push_back(r.type == REC_NODE ? node_ball(r) : prim_world_ball(r.type, r.inv, out.extras[r.extra].f));
-    if (out.recs.size() >= (1u << kLRefShift)) {
+    RT_PACK_MARK(4);
+    const size_t n_top = front.size();
+    const size_t total = std::max<size_t>(1, n_top + (out.has_bvh ? 2 * b.ids.size() - 1 : 0));
+    if (total >= (1u << kLRefShift)) {
         err = "too many records for the compact streams";
         return RT_ERR_CAPACITY;
     }
-    {  // the compact twin of every record, canonical order (stream 0 of the lane-mode walks)
-        std::vector<LNode> canon;
-        for (size_t i = 0; i < out.recs.size(); ++i) {
-            const DPrim& r = out.recs[i];
-            LNode ln{};
-            if (r.type == REC_NODE) {
-                for (int k = 0; k < 6; ++k) ln.inv[k] = r.inv[k];
-                ln.next = r.material;
-                ln.ref = REC_NODE << kLRefShift;
-            } else {
-                const HostBox box = prim_world_box(r.type, r.inv, out.extras[r.extra].f);
-                for (int k = 0; k < 3; ++k) {
-                    ln.inv[k] = box.bounded ? widen(std::nextafter(static_cast<float>(box.mn[k]), -INFINITY), false) : -INFINITY;
-                    ln.inv[3 + k] = box.bounded ? widen(std::nextafter(static_cast<float>(box.mx[k]), INFINITY), true) : INFINITY;
-                }
-                ln.next = static_cast<uint32_t>(i) + 1u;
-                ln.ref = (r.type << kLRefShift) | static_cast<uint32_t>(i);
-            }
-            canon.push_back(ln);
-        }
-        out.lnodes = canon;
-        if (out.has_bvh) {  // + the seven other direction orders of the same tree
-            for (uint32_t oct = 1; oct < 8; ++oct) {
-                std::vector<LNode> dst(canon.begin(), canon.begin() + n_top);
-                b.emit_lane(root, oct, dst, canon);
-                if (dst.size() != canon.size()) return bad("internal: direction-ordered stream of the wrong length");
-                out.lnodes.insert(out.lnodes.end(), dst.begin(), dst.end());
-            }
-        }
+    out.n_items = static_cast<uint32_t>(n_top + (out.has_bvh ? 2 * b.ids.size() - 1 : 0));
+    out.n_top = static_cast<uint32_t>(n_top);
+    const uint32_t n_streams = out.has_bvh && host_streams ? 8u : 1u;  // canonical order (+ the seven other direction orders)
+    out.recs.resize(total), out.order.resize(total), out.gate.resize(total);
+    out.lnodes.resize(total * n_streams);
+    if (out.n_items == 0) {  // the padding record of an empty scene (never walked)
+        out.recs[0] = DPrim{}, out.order[0] = 0u, out.gate[0] = kNoGate, out.lnodes[0] = BvhBuild::prim_lnode(false, nullptr, nullptr, 0u, 0u, 1u);
     }
+    for (size_t i = 0; i < n_top; ++i) {
+        const uint32_t item = front[i];
+        const DPrim r = src.record(d->item_ref[item]);
+        out.recs[i] = r, out.order[i] = item, out.gate[i] = item_gate[item];
+        const HostBox pb = prim_world_box(r.type, r.inv, out.extras[r.extra].f);
+        const LNode ln = BvhBuild::prim_lnode(pb.bounded, pb.mn, pb.mx, r.type, static_cast<uint32_t>(i), static_cast<uint32_t>(i) + 1u);
+        for (uint32_t o = 0; o < n_streams; ++o) out.lnodes[o * total + i] = ln;
+    }
+    RT_PACK_MARK(5);
+    if (out.has_bvh) {
+        b.out = &out, b.src = &src, b.item_gate = &item_gate;
+        b.n_streams = n_streams, b.total = total;
+        b.run(static_cast<uint32_t>(n_top));
+    }
+    RT_PACK_MARK(6);
+    out.bound.resize(total);
+    parallel_chunks(total, 1u << 14, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const DPrim& r = out.recs[i];
+            out.bound[i] = r.type == REC_NODE ? node_ball(r) : prim_world_ball(r.type, r.inv, out.extras[r.extra].f);
+        }
+    });
+    RT_PACK_MARK(7);
     if (out.has_f64) {  // record i of the stream is the primitive of item order[i]
         out.xprims.resize(out.recs.size());
-        for (size_t i = 0; i < out.n_items; ++i) {
-            if (out.recs[i].type == REC_NODE) continue;
-            const uint32_t ref = d->item_ref[out.order[i]];
-            std::memcpy(out.xprims[i].inv, d->prim_inv64 + 12 * static_cast<size_t>(ref), sizeof(out.xprims[i].inv));
-        }
+        parallel_chunks(out.n_items, 1u << 14, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                if (out.recs[i].type == REC_NODE) continue;
+                const uint32_t ref = d->item_ref[out.order[i]];
+                std::memcpy(out.xprims[i].inv, d->prim_inv64 + 12 * static_cast<size_t>(ref), sizeof(out.xprims[i].inv));
+            }
+        });
     }
     if (out.xprims.empty()) out.xprims.push_back(XPrim{});
     if (out.xpats.empty()) out.xpats.push_back(XPattern{});
@@ -637,6 +840,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         }
         out.xlights.push_back(xl);
     }
+    RT_PACK_MARK(8);
     out.n_lights = d->n_lights;
     if (out.lights.empty()) out.lights.push_back(DLight{}), out.xlights.push_back(XLight{});
     return RT_OK;

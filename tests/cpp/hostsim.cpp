@@ -697,6 +697,22 @@ extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_de
 }
 
 // ---------------------------------------------------------------------------------------------
+// pack_scene's walk streams with the seven direction orders laid out on the HOST (what rt_scene_create makes on the GPU
+// must equal them byte for byte).  out may be null to ask for the size.
+extern "C" int hostsim_pack_streams(const rt_scene_desc* desc, void* out, size_t cap, size_t* bytes_out) {
+    PackedScene ps;
+    std::string err;
+    const int rc = pack_scene(desc, ps, err, /*host_streams=*/true);
+    if (rc != RT_OK) return rc;
+    const size_t bytes = ps.lnodes.size() * sizeof(LNode);
+    if (bytes_out) *bytes_out = bytes;
+    if (out) {
+        if (cap < bytes) return RT_ERR_CAPACITY;
+        std::memcpy(out, ps.lnodes.data(), bytes);
+    }
+    return RT_OK;
+}
+
 // The direction-ordered compact streams of rt_pack.h (lane-mode walks of rt_kernel.h): structure of all eight, and
 // a closest-hit query through the ray's own stream against the same query through the canonical record stream, on
 // random rays.  out[0] = structural errors, out[1] = rays whose two answers differ, out[2] = records looked at in

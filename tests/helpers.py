@@ -111,6 +111,20 @@ def hostsim_render(example, options=None) -> np.ndarray:
     return out
 
 
+def hostsim_streams(scene_desc) -> np.ndarray:
+    """All eight walk streams of a scene laid out on the host by rt_pack.h ([8 * records, 8] uint32 words; one stream
+    for a scene without a hierarchy)."""
+    L = hostsim()
+    L.hostsim_pack_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t()
+    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), None, 0, C.byref(n))
+    assert rc == 0, rc
+    out = np.zeros((n.value // 32, 8), dtype=np.uint32)
+    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(n))
+    assert rc == 0, rc
+    return out
+
+
 def compare(test: np.ndarray, ref: np.ndarray, tol: float = 1e-4) -> dict:
     """Per-channel absolute error summary of an f32 image against the f64 oracle image."""
     d = np.abs(test.astype(np.float64) - ref)

@@ -162,3 +162,47 @@ def test_direction_ordered_streams_answer_like_the_canonical_stream(name, box):
     assert hits > 1000
     assert looked_own <= looked_canon, (looked_own, looked_canon)
     print(f"{name}: {n_items} records, per ray {looked_canon / 20000:.1f} records looked at in canonical order, {looked_own / 20000:.1f} in the ray's own")
+
+
+def _stream_hash(n_triangles: int, threads: int) -> str:
+    """sha1 of all eight host-made streams of a triangle soup, packed by a fresh process with `threads` workers."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C, hashlib, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {H.ROOT!r})\n"
+        "import helpers as H\n"
+        "keep = []\n"
+        f"d = H.triangle_soup_desc({n_triangles}, keep)\n"
+        "print(hashlib.sha1(H.hostsim_streams(C.pointer(d)).tobytes()).hexdigest())\n")
+    env = dict(os.environ, RT_AMD_THREADS=str(threads))
+    return subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.strip()
+
+
+def test_hierarchy_build_does_not_depend_on_the_number_of_threads():
+    """rt_pack.h builds the hierarchy with a pool of host threads (subtrees above 4096 primitives are handed out, nodes
+    above 131072 also split their own passes); every record's place is fixed by the tree, not by who wrote it: one
+    thread, three and eight give the same bytes.  200 000 triangles: two nodes are wide, dozens of subtrees are tasks."""
+    a, b, c = (_stream_hash(200_000, t) for t in (1, 3, 8))
+    assert a == b == c
+
+
+def test_streams_hold_the_split_axis_and_nest():
+    """Structure of the canonical stream the GPU derives the other seven from (lane_streams_kernel): a node's low ref bits
+    hold its split axis (3 = a pair of primitives), spans nest, a subtree over n primitives spans 2n - 1 records."""
+    ex = ExampleScene("multiple_glass_and_metallic_spheres", 64, 36)
+    st = H.hostsim_streams(ex.scene_desc)
+    n = st.shape[0] // 8
+    canon = st[:n]
+    is_node = (canon[:, 7] >> 29) == 6  # REC_NODE
+    assert is_node.any() and ((canon[is_node, 7] & 0x1FFFFFFF) <= 3).all()
+    idx = np.arange(n)
+    assert (canon[~is_node, 6] == idx[~is_node] + 1).all()
+    spans = canon[is_node, 6] - idx[is_node]
+    assert (spans % 2 == 1).all() and (spans >= 3).all()
+    pairs = is_node & ((canon[:, 7] & 3) == 3)
+    assert (canon[pairs, 6] - idx[pairs] == 3).all()
+    for o in range(1, 8):  # every stream holds the same primitive records once
+        s_o = st[o * n:(o + 1) * n]
+        prim = (s_o[:, 7] >> 29) != 6
+        assert np.array_equal(np.sort(s_o[prim, 7]), np.sort(canon[~is_node, 7]))

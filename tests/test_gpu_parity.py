@@ -430,6 +430,25 @@ def test_shared_frame_across_processes():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-500:])
 
 
+@pytest.mark.parametrize("what", ["multiple_glass_and_metallic_spheres", "cover_image", "obj_mesh", "soup"])
+def test_gpu_made_direction_streams_equal_the_host_made_ones(what):
+    """rt_scene_create uploads the canonical walk stream and lets the GPU lay out the other seven direction orders
+    (lane_streams_kernel); rt_pack.h can lay them out on the host too (the scalar spec does).  Same bytes."""
+    if what == "soup":
+        keep = []
+        d = H.triangle_soup_desc(30_000, keep)
+        desc = C.pointer(d)
+    else:
+        ex = ExampleScene(what, 64, 36)
+        desc = ex.scene_desc
+    sc = Scene(desc)
+    got = sc.read_streams()
+    want = H.hostsim_streams(desc)
+    assert got.shape == want.shape and got.shape[0] % 8 == 0
+    assert np.array_equal(got, want)
+    sc.close()
+
+
 def test_large_triangle_soup_matches_the_scalar_spec():
     """A stream of 100 000 triangles (hierarchy of ~200 000 records, EXOTIC + TREE kernel variant, one
     point light): far beyond any example scene; the device walk must agree with the scalar spec."""
