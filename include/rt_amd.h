@@ -221,9 +221,10 @@ int rt_scene_reserve(rt_scene* scene, uint32_t hsize, uint32_t rows);
 int rt_scene_variant(const rt_scene* scene, uint32_t* flags_out);
 
 /* The scene's walk streams as the device holds them (tests and tools; no counterpart in the reference): 32-byte
- * records {float box[6]; uint32 next; uint32 ref}, the canonical order first, then — for a scene with a hierarchy —
- * the seven other direction orders, which the GPU lays out itself at rt_scene_create.  out may be NULL to ask for the
- * size; *bytes_out receives it.  RT_ERR_CAPACITY if cap is too small.  Synchronous. */
+ * records {float box[6]; uint32 next; uint32 ref}.  A scene with a hierarchy: the eight direction orders of the stream,
+ * which the GPU lays out itself at rt_scene_create, then the canonical order, then the eight staged tops (16 records
+ * each) that the lane-mode kernels copy into LDS; any other scene: the canonical order alone.  out may be NULL to ask
+ * for the size; *bytes_out receives it.  RT_ERR_CAPACITY if cap is too small.  Synchronous. */
 int rt_scene_read_streams(const rt_scene* scene, void* out, size_t cap, size_t* bytes_out);
 
 /* Number of output rows a call with these options produces (<= camera vsize). */
@@ -248,7 +249,7 @@ int rt_output_rows(const rt_camera_desc* camera, const rt_options* options, uint
  *                     stats_out may be NULL.
  *   rt_render_u8:     (ABI 3) Camera::render followed by Canvas::to_image (canvas.rs:31-45) in one call, for
  *                     callers that only want the 8-bit image — what every example of the reference does
- *                     (examples/*.rs: `camera.render(&world).to_image()`): the frame is quantised on the device
+ *                     (the examples: `camera.render(&world).to_image()`): the frame is quantised on the device
  *                     and ONE byte per channel crosses PCIe instead of four.  rgb8_out_host: rows * hsize * 3
  *                     bytes.  Bit-identical to rt_render + rt_quantize_u8. */
 int rt_render_device(rt_scene* scene, const rt_camera_desc* camera, const rt_options* options,

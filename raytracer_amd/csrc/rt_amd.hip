@@ -338,7 +338,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     PackedScene ps;
     std::string err;
     const auto t_start = std::chrono::steady_clock::now();
-    int rc = pack_scene(desc, ps, err, /*host_streams=*/false);
+    const bool staged_top = RT_LDS_TOP != 0 && !std::getenv("RT_AMD_NO_TOP");  // (N1, rt_kernel.h: an experiment; the variable: its A/B timings)
+    int rc = pack_scene(desc, ps, err, /*host_streams=*/false, staged_top);
     if (rc != RT_OK) return fail(rc, err);
     const auto t_packed = std::chrono::steady_clock::now();
     int ndev = 0;
@@ -353,15 +354,33 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.order, &s->k.order, s->owned);
     if (rc == RT_OK) rc = upload(ps.gate, &s->k.gate, s->owned);
     if (rc == RT_OK) rc = upload(ps.bound, &s->k.bound, s->owned);
-    if (rc == RT_OK) rc = upload(ps.lnodes, &s->k.lnodes, s->owned, ps.has_bvh ? 8 : 1);
-    if (rc == RT_OK && ps.has_bvh) {  // the other seven direction orders of the hierarchy, laid out by the GPU
+    if (rc == RT_OK && !ps.has_bvh) {
+        rc = upload(ps.lnodes, &s->k.lnodes, s->owned);
+        s->k.lcanon = s->k.lnodes, s->k.top = s->k.lnodes, s->k.top_k = 0u;
+    }
+    if (rc == RT_OK && ps.has_bvh) {
+        // one allocation: the eight direction orders (laid out by the GPU), the canonical stream, the eight top regions
         const uint32_t n = static_cast<uint32_t>(ps.lnodes.size());
-        if (ps.n_top >= n || (ps.lnodes[ps.n_top].ref >> kLRefShift) != REC_NODE) rc = fail(RT_ERR_BAD_ARGUMENT, "internal: the hierarchy has no root record");
-        else {
-            hipLaunchKernelGGL(lane_streams_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, const_cast<LNode*>(s->k.lnodes), n, ps.n_top);
-            hipError_t e = hipGetLastError();
+        const uint32_t* d_ret = nullptr;
+        LNode* base = nullptr;
+        if (ps.n_top >= n || (ps.lnodes[ps.n_top].ref >> kLRefShift) != REC_NODE || ps.top.size() != 8u * kTopK) rc = fail(RT_ERR_BAD_ARGUMENT, "internal: the hierarchy has no root record");
+        if (rc == RT_OK) rc = upload(ps.portal_ret, &d_ret, s->owned);
+        if (rc == RT_OK) {
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), (9 * static_cast<size_t>(n) + 8u * kTopK) * sizeof(LNode));
+            if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(streams)");
+            else s->owned.push_back(base);
+        }
+        if (rc == RT_OK) {
+            LNode* canon = base + 8 * static_cast<size_t>(n);
+            hipError_t e = hipMemcpy(canon, ps.lnodes.data(), static_cast<size_t>(n) * sizeof(LNode), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(canon + n, ps.top.data(), 8u * kTopK * sizeof(LNode), hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(lane_streams_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, canon, n, ps.n_top, d_ret, base);
+                e = hipGetLastError();
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) rc = hip_fail(e, "lane_streams_kernel");
+            s->k.lnodes = base, s->k.lcanon = canon, s->k.top = canon + n, s->k.top_k = ps.top_k;
         }
     }
     if (rc == RT_OK) rc = upload(ps.gates, &s->k.gates, s->owned);
@@ -432,7 +451,8 @@ int rt_scene_variant(const rt_scene* s, uint32_t* flags_out) {
 
 int rt_scene_read_streams(const rt_scene* s, void* out, size_t cap, size_t* bytes_out) {
     if (!s || !bytes_out) return fail(RT_ERR_BAD_ARGUMENT, "rt_scene_read_streams: null argument");
-    const size_t bytes = static_cast<size_t>(s->k.has_bvh ? 8u : 1u) * std::max<uint32_t>(s->k.n_items, 1u) * sizeof(LNode);
+    const size_t n_rec = std::max<uint32_t>(s->k.n_items, 1u);
+    const size_t bytes = (s->k.has_bvh ? 9 * n_rec + 8u * kTopK : n_rec) * sizeof(LNode);
     *bytes_out = bytes;
     if (!out) return RT_OK;
     if (cap < bytes) return fail(RT_ERR_CAPACITY, "rt_scene_read_streams: the buffer is too small");

@@ -57,45 +57,13 @@ __global__ void quantize_kernel(const float* __restrict__ rgb, size_t n, uint8_t
     for (; i < n; i += stride) out[i] = quantize_u8(rgb[i]);  // canvas.rs:37-39
 }
 
-// The seven other direction-ordered LNode streams (rt_math.h, rt_pack.h BvhBuild) from the canonical one, which is
-// streams[0, n): one thread per record walks down from the root to its own record — a subtree is the span [p, next(p)) of
-// the canonical stream, its low child starts at p + 1 and its high child right after the low child's span — and adds up
-// where that path leads in each of the other orders (far child first where bit `axis` of the stream's number is set; the
-// split axis sits in the low bits of a node's ref, kLeafAxis = no change).  Then it stores its record there, with the
-// skip link of that stream.  A walk takes the tree's depth in steps; `guard` ends it whatever the links say.
-__global__ void lane_streams_kernel(LNode* __restrict__ streams, uint32_t n, uint32_t n_top) {
+// The eight direction-ordered LNode streams (rt_math.h lane_place) from the canonical one: one thread per record walks
+// down from the root to its own record (the tree's depth in steps; `guard` in lane_place ends a walk whatever the links
+// say) and stores the record at its place in each order, with that order's skip link.
+__global__ void lane_streams_kernel(const LNode* __restrict__ canon, uint32_t n, uint32_t n_top, const uint32_t* __restrict__ portal_ret,
+                                    LNode* __restrict__ streams) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const LNode me = streams[i];
-    if (i < n_top) {  // in front of the root: the same place in every stream
-        for (uint32_t o = 1; o < 8; ++o) streams[static_cast<size_t>(o) * n + i] = me;
-        return;
-    }
-    const uint32_t my_span = (me.ref >> kLRefShift) == REC_NODE ? me.next - i : 1u;
-    uint32_t pos[8];
-    for (uint32_t o = 1; o < 8; ++o) pos[o] = n_top;
-    uint32_t p = n_top;
-    for (int guard = 0; p != i && guard < 512; ++guard) {
-        const uint32_t p_end = streams[p].next, axis = streams[p].ref & 3u;
-        const uint32_t l = p + 1u;
-        if (l >= n) break;
-        const LNode low = streams[l];
-        const uint32_t span_l = (low.ref >> kLRefShift) == REC_NODE ? low.next - l : 1u;
-        const uint32_t r = l + span_l, span_r = p_end - r;
-        const bool high = i >= r;
-        for (uint32_t o = 1; o < 8; ++o) {
-            const bool flip = ((o >> axis) & 1u) != 0u;
-            pos[o] += 1u + (high ? (flip ? 0u : span_l) : (flip ? span_r : 0u));
-        }
-        p = high ? r : l;
-    }
-    if (p != i) return;  // (links that do not nest: pack_scene never makes them)
-    for (uint32_t o = 1; o < 8; ++o) {
-        if (pos[o] >= n || my_span > n - pos[o]) continue;
-        LNode out = me;
-        out.next = pos[o] + my_span;
-        streams[static_cast<size_t>(o) * n + pos[o]] = out;
-    }
+    if (i < n) lane_place(canon, n, n_top, portal_ret, i, streams);
 }
 
 }  // namespace rtk

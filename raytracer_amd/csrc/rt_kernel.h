@@ -118,7 +118,9 @@ struct KScene {
     const uint32_t* order;  // per record: world.objects position of the primitive (tie order)
     const uint32_t* gate;   // per record: innermost enclosing Group of the caller's tree, or kNoGate
     const DBound* bound;    // per record: world-space bounding ball (shaft tests)
-    const LNode* lnodes;    // per record: box + skip link in 32 bytes (lane-mode walks)
+    const LNode* lnodes;    // per record: box + skip link in 32 bytes (lane-mode walks): the eight direction orders (one stream without a hierarchy)
+    const LNode* lcanon;    // the same in canonical order (walks whose enter test follows no ray)
+    const LNode* top;       // the staged top of each direction order (rt_math.h kTopK), 8 x kTopK records
     const DGate* gates;
     const DExtra* extras;
     const DMaterial* mats;
@@ -133,6 +135,7 @@ struct KScene {
     uint32_t n_items, n_lights;
     uint32_t has_gates, has_bvh;
     uint32_t any_spawn;  // some material is reflective or transparent (no path has a second node otherwise)
+    uint32_t top_k;      // records in use per staged top; 0 = none (the walks start at record 0 of the stream)
 };
 struct KParams {
     KScene sc;
@@ -255,22 +258,75 @@ __device__ __forceinline__ void traverse_masked(const KScene& sc, uint32_t self_
 #ifndef RT_LANE_WALK
 #define RT_LANE_WALK 8
 #endif
-template <class Enter, class Visit>
-__device__ __forceinline__ void traverse_lane(const KScene& sc, const LNode* stream, uint32_t self_prim, bool live, uint32_t i, Enter&& enter_node,
-                                              Visit&& visit) {
+//
+// The staged top (N1; rt_math.h kTopK) — an experiment that stays switched off (RT_LDS_TOP = 0): measured on C4 it wins
+// 3.7 % when on against off in the same binary and the code that carries it costs 2.8 %, and the kernels at 5 waves a SIMD
+// lose a wave to its LDS (profiles/r03_lds_top.txt).  With it a walk in a ray's own order starts in the TOP REGION of that
+// order: indices above n are records of the region, a portal whose box the ray meets leads to the subtree's first child
+// in memory, and the links that leave that subtree lead back into the region.  TOP = 1: the region is read from memory
+// like the stream; TOP = 2: from LDS, where the wave copied all eight regions when it started (RT_TOP_FIRST: the steps
+// inside the region go first — while some lane stands in the region only those lanes step).  TOP = 0: a stream from
+// record 0, no region.
+#ifndef RT_LDS_TOP
+#define RT_LDS_TOP 0  // 1 = regions in memory; 2 = in LDS for the kernels whose occupancy 4 KB more a wave does not lower
+#endif
+#ifndef RT_TOP_FIRST
+#define RT_TOP_FIRST 0
+#endif
+__device__ __forceinline__ LNode* staged_top() {
+    __shared__ LNode s_top[8 * kTopK];
+    return s_top;
+}
+// Record j of the staged tops, read as LDS (two ds_read_b128).  Through a plain pointer the compiler merges this load
+// with the stream's load of the other branch into ONE load through a generic pointer — a flat_load, which is what the
+// first measurements of N1 ran on (profiles/r03_lds_top.txt).
+__device__ __forceinline__ LNode staged_top_record(uint32_t j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const U4 LdsU4;
+    LdsU4* t = (LdsU4*)staged_top();
+    const U4 a = t[2u * j], b = t[2u * j + 1u];
+    LNode nd;
+    nd.inv[0] = __uint_as_float(a.x), nd.inv[1] = __uint_as_float(a.y), nd.inv[2] = __uint_as_float(a.z), nd.inv[3] = __uint_as_float(a.w);
+    nd.inv[4] = __uint_as_float(b.x), nd.inv[5] = __uint_as_float(b.y), nd.next = b.z, nd.ref = b.w;
+    return nd;
+#else  // (the host pass of the compiler only parses this)
+    return staged_top()[j];
+#endif
+}
+template <int TOP, class Enter, class Visit>
+__device__ __forceinline__ void traverse_lane(const KScene& sc, const LNode* stream, [[maybe_unused]] const LNode* top, [[maybe_unused]] uint32_t top_at,
+                                              uint32_t self_prim, bool live, uint32_t i, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
-    bool go = live && i < n;
+    bool go = live && (TOP == 0 ? i < n : i != n);
     while (wave_any(go)) {
         uint32_t cand = kNoPrim;
 #pragma unroll 1
         for (int k = 0; k < RT_LANE_WALK; ++k) {
-            if (go && cand == kNoPrim) {
-                const LNode nd = stream[i];
+            bool mine = go && cand == kNoPrim;
+            LNode nd;
+            if (TOP == 2 && RT_TOP_FIRST && wave_any(mine && i > n)) {
+                mine = mine && i > n;
+                if (mine) nd = staged_top_record(top_at + (i - n - 1u));
+            } else if (TOP == 2 && !RT_TOP_FIRST) {
+                if (mine && i > n) nd = staged_top_record(top_at + (i - n - 1u));
+                else if (mine) nd = stream[i];
+            } else if (mine) {
+                nd = *((TOP == 1 && i > n) ? top + (i - n - 1u) : stream + i);
+            }
+            if (mine) {
                 const bool in = enter_node(i, nd);
-                const bool is_node = (nd.ref >> kLRefShift) == REC_NODE;
-                cand = (in && !is_node) ? (nd.ref & kLRefMask) : kNoPrim;
-                i = (is_node && !in) ? nd.next : i + 1u;
-                go = i < n;
+                const uint32_t type = nd.ref >> kLRefShift;
+                if constexpr (TOP == 0) {
+                    const bool is_node = type == REC_NODE;
+                    cand = (in && !is_node) ? (nd.ref & kLRefMask) : kNoPrim;
+                    i = (is_node && !in) ? nd.next : i + 1u;
+                    go = i < n;
+                } else {
+                    cand = (in && type < REC_NODE) ? (nd.ref & kLRefMask) : kNoPrim;
+                    i = (in && type == REC_NODE) ? i + 1u : ((in && type == REC_PORTAL) ? (nd.ref & kLRefMask) : nd.next);
+                    go = i != n;
+                }
             }
             if (!wave_any(go && cand == kNoPrim)) break;
         }
@@ -293,7 +349,7 @@ __device__ __forceinline__ uint32_t octant_of(V3 d) { return (d.x < 0.0f ? 1u : 
 // shaft tests).  Without LANE: the union walk, records through scalar loads.  (A wave that switches from one to the
 // other at run time measured slower than either: both loops with their inlined visitors in one kernel cost the
 // union walk 20 % through register pressure, profiles/r02_lane_mode.txt.)
-template <bool TREE, bool LANE, bool OWN_ORDER, class Enter, class Visit>
+template <bool TREE, int LANE, bool OWN_ORDER, class Enter, class Visit>
 __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, bool live, V3 dir, Enter&& enter_node, Visit&& visit) {
     const uint32_t n = sc.n_items;
     if (n == 0u) return;
@@ -301,8 +357,14 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
         traverse_masked<false>(sc, self_prim, live, ~0ull, visit);
         return;
     }
-    if (LANE) {
-        traverse_lane(sc, OWN_ORDER ? sc.lnodes + octant_of(dir) * n : sc.lnodes, self_prim, live, 0u, enter_node, visit);
+    if constexpr (LANE != 0) {
+        if constexpr (OWN_ORDER) {
+            const uint32_t oct = octant_of(dir);
+            constexpr int kTop = RT_LDS_TOP == 0 ? 0 : LANE;
+            traverse_lane<kTop>(sc, sc.lnodes + oct * n, sc.top + oct * kTopK, oct * kTopK, self_prim, live, (kTop && sc.top_k) ? n + 1u : 0u, enter_node, visit);
+        } else {
+            traverse_lane<0>(sc, sc.lcanon, nullptr, 0u, self_prim, live, 0u, enter_node, visit);
+        }
         return;
     }
     uint32_t i = 0;
@@ -341,7 +403,7 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
 // NEAR (the kernels with the f64 chain): `unsure` also reports whether some test on the way was a near thing — a grazed
 // sphere or cube edge, the own sphere at the terminator (rt_math.h occludes_prim_near): this light's count at this node
 // is then worked out again by the fix kernel.
-template <bool EXOTIC, bool TREE, bool LANE, bool NEAR>
+template <bool EXOTIC, bool TREE, int LANE, bool NEAR>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask, bool& unsure) {
     bool occ = false;
     [[maybe_unused]] bool near = false;
@@ -477,6 +539,10 @@ struct Ray64 {
 template <bool STATS, bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool LANE = false, bool SPAWN = true>
 __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EXACT, SPAWN)) void render_kernel(const KParams P) {
     static_assert(TREE || !LANE, "lane-mode walks need a hierarchy");
+    // 2 = the staged tops live in LDS (RT_LDS_TOP = 2): the kernels with the f64 chain and no area-light code run 4 waves
+    // a SIMD at 128 VGPRs with 6 KB of LDS a wave, and 4 KB more still fits 16 waves a CU; the others would lose a wave or
+    // two a SIMD to it (the FP32-only hierarchy kernels 5 -> 3: 1 M triangles 1.88 -> 2.32 ms, profiles/r03_lds_top.txt)
+    constexpr int kLane = LANE ? ((EXACT && !AREA && RT_LDS_TOP == 2) ? 2 : 1) : 0;
 #ifdef RT_ORDER
     constexpr uint32_t kOrder0 = RT_ORDER;  // experiments
 #else
@@ -489,6 +555,19 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     const uint32_t wave = P.tile_order ? uni(P.tile_order[wave_id]) : wave_id;  // the tile slot this wave renders
     uint32_t n_rounds = 0, n_visibility = 0;  // rounds of the path loop, points x light chunks that needed shadow rays: the tile's cost ("Tile order" below)
     const KScene& sc = P.sc;
+    if constexpr (kLane == 2) {  // the staged tops of the eight direction orders: 4 KB, 64 bytes a lane
+        static_assert(8 * kTopK * sizeof(LNode) == 64 * 4 * sizeof(uint4), "one wave copies the staged tops with four 16-byte loads a lane");
+        if (sc.top_k) {
+            uint4* dst = reinterpret_cast<uint4*>(staged_top());
+            const uint4* src = reinterpret_cast<const uint4*>(sc.top);
+            if (threadIdx.x < 64u) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) dst[k * 64u + threadIdx.x] = src[k * 64u + threadIdx.x];
+            }
+            if (kBlockThreads > 64u) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
 
     uint32_t x, yl, gy;
     const bool valid = pixel_of_lane(P, kOrder, wave, lane, x, yl, gy);
@@ -632,7 +711,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     else intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, emit);
                     return true;
                 };
-            traverse<TREE, LANE, true>(sc, cur.self, live, cur.d, trace_enter, trace_visit);
+            traverse<TREE, kLane, true>(sc, cur.self, live, cur.d, trace_enter, trace_visit);
         };
         // Selection in f64 among what FP32 could not order, and for every node that spawns children.  Returns
         // whether f64 found none of the candidates in front of the ray (then they are left out of a second search).
@@ -717,7 +796,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
-            traverse<TREE, LANE, false>(
+            traverse<TREE, kLane, false>(
                 sc, cur.self, need_n, cur.d,
                 [&](uint32_t, const auto& nd) {
                     // crossings behind the origin count too (sorted list), those beyond the hit never
@@ -901,7 +980,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 Ray sr;
                 sr.o = p_over, sr.d = tl * inv_dist, sr.self = h_prim(), sr.q = h_q(), sr.dq = h_dq();
                 bool unsure = false;
-                const bool occ = occluded<EXOTIC, TREE, LANE, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull, unsure);
+                const bool occ = occluded<EXOTIC, TREE, kLane, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast && matters && !(RT_EXP & 128), false, ~0ull, unsure);
                 lit = occ ? 0.0f : 1.0f;
                 if constexpr (EXACT) emit_fix((unsure || qedge) && cast && matters, li, lit, sum_d, sum_s, lc, 1.0f);
                 if (STATS && cast) c_shadow++;
@@ -951,7 +1030,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         far_front = pb.far_front, no_spec = pb.no_spec || park[13 * kBlockThreads] == 0.0f;  // no specular term at all
                     }
                     blockers = 0;
-                    traverse<TREE, LANE, false>(
+                    traverse<TREE, kLane, false>(
                         sc, h_prim(), walks, sh.D,
                         [&](uint32_t i, const auto&) {  // (lane mode asks for primitives too: the same ball test as the visitor's)
                             const DBound b = sc.bound[i];
@@ -1224,7 +1303,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         const bool occ = cast && dist > 1e30f;
 #else
                         bool unsure = false;
-                        const bool occ = occluded<EXOTIC, TREE, LANE, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast, by_mask, pass_mask, unsure);
+                        const bool occ = occluded<EXOTIC, TREE, kLane, EXACT && !RT_NO_NEAR>(sc, sr, dist, cast, by_mask, pass_mask, unsure);
 #endif
                         const unsigned long long b = __ballot(con && !occ);
                         const int lead = static_cast<int>(my_slot << glog);

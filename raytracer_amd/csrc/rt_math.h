@@ -77,6 +77,21 @@ constexpr uint32_t kLRefMask = (1u << kLRefShift) - 1u;
 // (a node's low bits: the axis it was split along, 0..2, or kLeafAxis for a node over two primitives, whose order is the
 // same in every stream.  The walks never look at them; the kernel that lays the direction-ordered streams out does.)
 constexpr uint32_t kLeafAxis = 3u;
+
+// The staged top of the hierarchy (N1).  The hierarchy walks of the lane-mode kernels wait on dependent loads, and what
+// most of their steps look at is the same few records: the primitives in front of the root and the top of the tree.  The
+// scene therefore carries, per direction order, a TOP REGION of at most kTopK records that every wave copies into LDS
+// when it starts: those primitives, the largest nodes of the tree in that order's pre-order (rt_pack.h build_top picks
+// them: the node with the most primitives below it is opened next), and where the region ends a PORTAL per subtree left
+// out — the subtree root's box, and the place of its first child in that order's stream in memory.  A walk starts in
+// the region; a lane whose ray meets a portal's box goes on in memory, and the skip links that would leave that subtree
+// lead back to the record after the portal (lane_place below writes them).  Indices: 0..n-1 = the stream in memory,
+// n = the end of the walk, n + 1 + j = record j of the region.
+constexpr uint32_t kTopK = 16u;        // 8 orders x 16 records x 32 bytes = 4 KB of LDS a wave (what 16 waves a CU leave)
+constexpr uint32_t kPortalFlag = 4u;   // canonical stream, a node's ref: bit 2 = a portal leads here, bits 3.. = which
+constexpr uint32_t kPortalShift = 3u;
+constexpr uint32_t kNoPortal = 0xFFFFFFFFu;
+
 struct DExtra {  // 128 B: cylinder {min,max,closed}; triangle {v0,e0,e1,normal,n0,n1,n2}
     float f[32];
 };
@@ -108,10 +123,59 @@ struct DCamera {
 };
 
 enum : uint32_t { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_CUBE = 2, PRIM_CYLINDER = 3, PRIM_TRIANGLE = 4, PRIM_SMOOTH = 5,
-                  REC_NODE = 6 };
+                  REC_NODE = 6,
+                  REC_PORTAL = 7 };  // (LNode records of a staged top only, below)
 enum : uint32_t { PAT_SOLID = 0, PAT_STRIPE = 1, PAT_GRADIENT = 2, PAT_RING = 3, PAT_CHECKER = 4 };
 constexpr uint32_t kItemNode = 0x80000000u;
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+
+// Lays record i of the canonical stream out in the eight direction-ordered streams (streams[o * n + ...]): walks down
+// from the root to the record — a subtree is the span [p, next(p)) of the canonical stream, its low child starts at p + 1
+// and its high child right after the low child's span — adding up where that path leads in each order (far child first
+// where bit `axis` of the order's number is set).  portal_ret[8 * id + o] = where the walks of order o go on after the
+// subtree of portal `id`.  One thread of lane_streams_kernel (rt_aux_kernels.h) per record, or a host loop (rt_pack.h).
+RT_HD void lane_place(const LNode* canon, uint32_t n, uint32_t n_top, const uint32_t* portal_ret, uint32_t i, LNode* streams) {
+    const LNode me = canon[i];
+    if (i < n_top) {  // in front of the root: the same place in every stream
+        for (uint32_t o = 0; o < 8u; ++o) streams[static_cast<size_t>(o) * n + i] = me;
+        return;
+    }
+    const bool me_node = (me.ref >> kLRefShift) == REC_NODE;
+    const uint32_t my_span = me_node ? me.next - i : 1u;
+    uint32_t pos[8], sub_end[8];
+    for (uint32_t o = 0; o < 8u; ++o) pos[o] = n_top, sub_end[o] = 0u;
+    uint32_t portal = kNoPortal;
+    uint32_t p = n_top;
+    for (int guard = 0; guard < 512; ++guard) {
+        const uint32_t p_ref = canon[p].ref, p_end = canon[p].next;
+        const bool p_node = (p_ref >> kLRefShift) == REC_NODE;
+        if (p_node && (p_ref & kPortalFlag) && portal == kNoPortal) {
+            portal = (p_ref & kLRefMask) >> kPortalShift;
+            for (uint32_t o = 0; o < 8u; ++o) sub_end[o] = pos[o] + (p_end - p);
+        }
+        if (p == i || !p_node) break;
+        const uint32_t axis = p_ref & 3u, l = p + 1u;
+        if (l >= n) break;
+        const LNode low = canon[l];
+        const uint32_t span_l = (low.ref >> kLRefShift) == REC_NODE ? low.next - l : 1u;
+        const uint32_t r = l + span_l, span_r = p_end - r;
+        const bool high = i >= r;
+        for (uint32_t o = 0; o < 8u; ++o) {
+            const bool flip = ((o >> axis) & 1u) != 0u;
+            pos[o] += 1u + (high ? (flip ? 0u : span_l) : (flip ? span_r : 0u));
+        }
+        p = high ? r : l;
+    }
+    if (p != i) return;  // (links that do not nest: pack_scene never makes them)
+    for (uint32_t o = 0; o < 8u; ++o) {
+        if (pos[o] >= n || my_span > n - pos[o]) continue;
+        LNode out = me;
+        out.next = pos[o] + my_span;
+        if (portal != kNoPortal && out.next == sub_end[o]) out.next = portal_ret[8u * portal + o];
+        if (me_node) out.ref = (REC_NODE << kLRefShift) | (me.ref & 3u);
+        streams[static_cast<size_t>(o) * n + pos[o]] = out;
+    }
+}
 
 struct V3 {
     float x, y, z;

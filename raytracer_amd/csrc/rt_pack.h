@@ -58,9 +58,13 @@ struct PackedScene {
     PodVec<uint32_t> order;   // per record: the primitive's position in world.objects order (nodes: 0)
     PodVec<uint32_t> gate;    // per record: innermost enclosing Group (index into gates) or kNoGate
     PodVec<DBound> bound;     // per record: world-space bounding ball (shaft tests)
-    // per record: the compact twin of the stream (lane-mode walks): the canonical order, then — only if the caller of
-    // pack_scene asked for them (host_streams) — the seven other direction orders; rt_scene_create makes those on the GPU
-    PodVec<LNode> lnodes;
+    PodVec<LNode> lnodes;     // per record: the compact twin of the stream, canonical order (lane-mode walks)
+    // the eight direction orders of it (8 x records; a scene with a hierarchy, and only if the caller of pack_scene asked
+    // for them — host_streams; rt_scene_create lets the GPU lay them out), and the staged top (rt_math.h kTopK)
+    PodVec<LNode> lstreams;
+    std::vector<LNode> top;           // 8 x kTopK
+    std::vector<uint32_t> portal_ret;  // 8 per portal
+    uint32_t top_k = 0;               // records in use per top region; 0 = no staged top
     uint32_t n_top = 0;           // records in front of the hierarchy's root (unbounded primitives)
     std::vector<DGate> gates;     // the caller's Groups
     PodVec<DExtra> extras;
@@ -314,11 +318,11 @@ struct PrimSource {
 //
 // A subtree over n primitives takes exactly 2n - 1 records (a bare record for a single primitive, a box record + two
 // primitives for a pair, 1 + left + right above that), so the place of every record in the canonical stream (pre-order,
-// low side of every split first) AND in the seven other direction-ordered streams (far child first where the ray's
-// direction is negative along the split axis) is known on the way DOWN.  The build therefore has no tree to keep and no
-// emission pass: each subtree writes its records where they belong, subtrees are independent, and a pool of host threads
-// takes them from a shared stack (big nodes also bin and partition their range with all threads).  The result does not
-// depend on the number of threads or on who built what.
+// low side of every split first) is known on the way DOWN.  The build therefore has no tree to keep and no emission
+// pass: each subtree writes its records where they belong, subtrees are independent, and a pool of host threads takes
+// them from a shared stack (big nodes also bin and partition their range with all threads).  The result does not
+// depend on the number of threads or on who built what.  (The direction-ordered streams of the lane-mode walks are
+// laid out from the canonical one afterwards: lane_place, rt_math.h — by the GPU in rt_scene_create.)
 struct BvhBuild {
     static constexpr int kBins = 16;
     static constexpr uint32_t kSpawn = 4096;     // subtrees above this many primitives are handed to the pool
@@ -333,15 +337,13 @@ struct BvhBuild {
         uint32_t lo, hi;  // items [lo, hi) ...
         uint32_t side;    // ... of buf[side]
         int depth;
-        uint32_t pos[8];  // first record of the subtree in each stream
+        uint32_t pos;     // first record of the subtree in the canonical stream
     };
     PodVec<Item> buf[2];        // the partitions scatter a range from one into the same range of the other
     std::vector<uint32_t> ids;  // item index of each bounded primitive
     PackedScene* out = nullptr;
     const PrimSource* src = nullptr;
     const std::vector<uint32_t>* item_gate = nullptr;
-    uint32_t n_streams = 1;  // 1: canonical stream only; 8: + the direction-ordered ones
-    size_t total = 0;        // records per stream
 
     // the pool
     std::mutex mu;
@@ -366,29 +368,27 @@ struct BvhBuild {
         ln.ref = (type << kLRefShift) | rec;
         return ln;
     }
-    void put_prim(const Item& it, const uint32_t* pos) {
-        const uint32_t item = ids[it.k], at = pos[0];
+    void put_prim(const Item& it, uint32_t at) {
+        const uint32_t item = ids[it.k];
         const DPrim r = src->record(src->d->item_ref[item]);
         out->recs[at] = r, out->order[at] = item, out->gate[at] = (*item_gate)[item];
-        for (uint32_t o = 0; o < n_streams; ++o) out->lnodes[o * total + pos[o]] = prim_lnode(true, it.mn, it.mx, r.type, at, pos[o] + 1u);
+        out->lnodes[at] = prim_lnode(true, it.mn, it.mx, r.type, at, at + 1u);
     }
     // axis: the split axis, or kLeafAxis for a pair of primitives (whose order no direction changes)
-    void put_node(const HostBox& box, uint32_t n, uint32_t axis, const uint32_t* pos) {
+    void put_node(const HostBox& box, uint32_t n, uint32_t axis, uint32_t pos) {
         DPrim node{};
         for (int k = 0; k < 3; ++k) {
             node.inv[k] = widen(std::nextafter(static_cast<float>(box.mn[k]), -INFINITY), false);
             node.inv[3 + k] = widen(std::nextafter(static_cast<float>(box.mx[k]), INFINITY), true);
         }
         node.type = REC_NODE;
-        node.material = pos[0] + 2u * n - 1u;  // skip link
-        out->recs[pos[0]] = node, out->order[pos[0]] = 0, out->gate[pos[0]] = kNoGate;
+        node.material = pos + 2u * n - 1u;  // skip link
+        out->recs[pos] = node, out->order[pos] = 0, out->gate[pos] = kNoGate;
         LNode ln{};
         for (int k = 0; k < 6; ++k) ln.inv[k] = node.inv[k];
         ln.ref = (REC_NODE << kLRefShift) | axis;
-        for (uint32_t o = 0; o < n_streams; ++o) {
-            ln.next = pos[o] + 2u * n - 1u;
-            out->lnodes[o * total + pos[o]] = ln;
-        }
+        ln.next = node.material;
+        out->lnodes[pos] = ln;
     }
     struct Bins {
         HostBox box[3][kBins];
@@ -431,9 +431,7 @@ struct BvhBuild {
         }
         if (n == 2) {
             put_node(box, n, kLeafAxis, t.pos);
-            uint32_t p1[8], p2[8];
-            for (uint32_t o = 0; o < n_streams; ++o) p1[o] = t.pos[o] + 1u, p2[o] = t.pos[o] + 2u;
-            put_prim(items[lo], p1), put_prim(items[lo + 1], p2);
+            put_prim(items[lo], t.pos + 1u), put_prim(items[lo + 1], t.pos + 2u);
             return;
         }
         // the bins of the three axes in one pass
@@ -528,13 +526,8 @@ struct BvhBuild {
             });
         }
         put_node(box, n, static_cast<uint32_t>(axis), t.pos);
-        const uint32_t nl = mid - lo, nr = hi - mid;
-        Task l{lo, mid, side, t.depth + 1, {}}, r{mid, hi, side, t.depth + 1, {}};
-        for (uint32_t o = 0; o < n_streams; ++o) {
-            const bool flip = ((o >> axis) & 1u) != 0;  // bit k of o set: the ray's direction is negative along axis k
-            l.pos[o] = t.pos[o] + 1u + (flip ? 2u * nr - 1u : 0u);
-            r.pos[o] = t.pos[o] + 1u + (flip ? 0u : 2u * nl - 1u);
-        }
+        const uint32_t nl = mid - lo;
+        const Task l{lo, mid, side, t.depth + 1, t.pos + 1u}, r{mid, hi, side, t.depth + 1, t.pos + 2u * nl};
         if (n > kSpawn) {
             push(r);
             push(l);
@@ -543,10 +536,9 @@ struct BvhBuild {
         subtree(l, push);
         subtree(r, push);
     }
-    // Builds the tree over buf[0][0, n) with its first record at `first` of every stream.
+    // Builds the tree over buf[0][0, n) with its first record at `first`.
     void run(uint32_t first) {
-        Task root{0, static_cast<uint32_t>(buf[0].size()), 0u, 0, {}};
-        for (uint32_t& p : root.pos) p = first;
+        const Task root{0, static_cast<uint32_t>(buf[0].size()), 0u, 0, first};
         buf[1].resize(buf[0].size());
         stack.push_back(root);
         open_tasks = 1;
@@ -584,6 +576,94 @@ struct BvhBuild {
     }
 };
 
+// The staged top of the hierarchy (rt_math.h kTopK): which nodes are opened — the one with the most records below it
+// next, the earlier one among equals — until the region is full, then the region of each direction order in that order's
+// pre-order.  Marks the portal roots in the canonical stream (canon[p].ref).  k = 0: no staging (no hierarchy, or more
+// primitives in front of the root than a region holds).
+struct TopRegions {
+    std::vector<LNode> recs;        // 8 x kTopK (unused records: zero)
+    std::vector<uint32_t> ret;      // 8 per portal: where the walks of each order go on after that portal's subtree
+    uint32_t k = 0;                 // records in use per region
+};
+inline TopRegions build_top(LNode* canon, uint32_t n, uint32_t n_top, bool has_bvh) {
+    TopRegions t;
+    t.recs.assign(8 * kTopK, LNode{});
+    t.ret.assign(8, 0u);
+    if (!has_bvh || n_top + 3u > kTopK || n_top >= n) return t;
+    auto is_node = [&](uint32_t p) { return (canon[p].ref >> kLRefShift) == REC_NODE; };
+    auto span = [&](uint32_t p) { return is_node(p) ? canon[p].next - p : 1u; };
+    std::vector<uint32_t> open;  // nodes opened (canonical positions)
+    std::vector<uint32_t> edge{n_top};
+    uint32_t count = n_top + 1u;
+    for (;;) {
+        size_t best = edge.size();
+        for (size_t e = 0; e < edge.size(); ++e)
+            if (is_node(edge[e]) && (best == edge.size() || span(edge[e]) > span(edge[best]) || (span(edge[e]) == span(edge[best]) && edge[e] < edge[best]))) best = e;
+        if (best == edge.size() || count + 2u > kTopK) break;
+        const uint32_t p = edge[best], l = p + 1u, r = l + span(l);
+        open.push_back(p);
+        edge[best] = l, edge.push_back(r);
+        count += 2u;
+    }
+    std::sort(edge.begin(), edge.end());
+    uint32_t n_portals = 0;
+    for (uint32_t p : edge)
+        if (is_node(p)) canon[p].ref |= kPortalFlag | (n_portals++ << kPortalShift);
+    t.ret.assign(8 * std::max(1u, n_portals), 0u);
+    t.k = count;
+    auto idx = [&](uint32_t j) { return j >= count ? n : n + 1u + j; };
+    for (uint32_t o = 0; o < 8u; ++o) {
+        LNode* reg = t.recs.data() + o * kTopK;
+        uint32_t j = 0;
+        for (; j < n_top; ++j) reg[j] = canon[j], reg[j].next = idx(j + 1u);
+        // pre-order of the opened part in this order; pos = the record's place in this order's stream in memory
+        struct Frame {
+            uint32_t p, pos;
+        };
+        std::vector<Frame> todo{{n_top, n_top}};
+        std::vector<uint32_t> close;  // region records of opened nodes
+        while (!todo.empty()) {
+            const Frame f = todo.back();
+            todo.pop_back();
+            const bool opened = std::find(open.begin(), open.end(), f.p) != open.end();
+            LNode rec = canon[f.p];
+            if (opened) {
+                rec.ref = REC_NODE << kLRefShift;
+                const uint32_t axis = canon[f.p].ref & 3u, l = f.p + 1u, r = l + span(l);
+                const bool flip = ((o >> axis) & 1u) != 0u;
+                const uint32_t first = flip ? r : l, second = flip ? l : r;
+                todo.push_back({second, f.pos + 1u + span(first)});
+                todo.push_back({first, f.pos + 1u});
+            } else if (is_node(f.p)) {
+                rec.ref = (REC_PORTAL << kLRefShift) | (f.pos + 1u);  // the subtree's first child, in this order's stream
+                t.ret[8u * ((canon[f.p].ref & kLRefMask) >> kPortalShift) + o] = idx(j + 1u);
+            }
+            rec.next = idx(j + 1u);  // (opened nodes: set below, once the size of what is under them is known)
+            reg[j] = rec;
+            if (opened) close.push_back(j);
+            ++j;
+        }
+        // skip links of the opened nodes: an opened node is followed by its two subtrees, whose leaves are the primitives
+        // and portals at the region's edge
+        for (const uint32_t at : close) {
+            uint32_t need = 1, q = at;
+            while (need) {
+                need = (reg[q].ref >> kLRefShift) == REC_NODE ? need + 1u : need - 1u;
+                ++q;
+            }
+            reg[at].next = idx(q);
+        }
+    }
+    return t;
+}
+// All eight direction-ordered streams from the canonical one, on the host (the scalar spec of the tests; rt_scene_create
+// lets the GPU do it): streams = 8 x n records.
+inline void place_streams_on_host(const LNode* canon, uint32_t n, uint32_t n_top, const uint32_t* portal_ret, LNode* streams) {
+    parallel_chunks(n, 1u << 12, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) lane_place(canon, n, n_top, portal_ret, static_cast<uint32_t>(i), streams);
+    });
+}
+
 #ifdef RT_PACK_TIMING  // (scratch/pack_time.cpp: where the time of a large scene goes)
 #include <chrono>
 inline double g_pack_marks[16];
@@ -594,7 +674,8 @@ inline double g_pack_marks[16];
 // Returns RT_OK or a negative rt_status; `err` receives the message.
 // host_streams: lay the seven other direction-ordered LNode streams out here as well (the host simulator of the tests);
 // rt_scene_create makes them on the GPU from the canonical one (lane_streams_kernel, rt_aux_kernels.h).
-inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err, bool host_streams = true) {
+// staged_top: pick the top regions of the lane-mode walks (rt_math.h kTopK); false = plain streams (experiments).
+inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err, bool host_streams = true, bool staged_top = true) {
     auto bad = [&](const char* m) {
         err = m;
         return static_cast<int>(RT_ERR_BAD_ARGUMENT);
@@ -766,9 +847,8 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     }
     out.n_items = static_cast<uint32_t>(n_top + (out.has_bvh ? 2 * b.ids.size() - 1 : 0));
     out.n_top = static_cast<uint32_t>(n_top);
-    const uint32_t n_streams = out.has_bvh && host_streams ? 8u : 1u;  // canonical order (+ the seven other direction orders)
     out.recs.resize(total), out.order.resize(total), out.gate.resize(total);
-    out.lnodes.resize(total * n_streams);
+    out.lnodes.resize(total);
     if (out.n_items == 0) {  // the padding record of an empty scene (never walked)
         out.recs[0] = DPrim{}, out.order[0] = 0u, out.gate[0] = kNoGate, out.lnodes[0] = BvhBuild::prim_lnode(false, nullptr, nullptr, 0u, 0u, 1u);
     }
@@ -778,13 +858,20 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
         out.recs[i] = r, out.order[i] = item, out.gate[i] = item_gate[item];
         const HostBox pb = prim_world_box(r.type, r.inv, out.extras[r.extra].f);
         const LNode ln = BvhBuild::prim_lnode(pb.bounded, pb.mn, pb.mx, r.type, static_cast<uint32_t>(i), static_cast<uint32_t>(i) + 1u);
-        for (uint32_t o = 0; o < n_streams; ++o) out.lnodes[o * total + i] = ln;
+        out.lnodes[i] = ln;
     }
     RT_PACK_MARK(5);
     if (out.has_bvh) {
         b.out = &out, b.src = &src, b.item_gate = &item_gate;
-        b.n_streams = n_streams, b.total = total;
         b.run(static_cast<uint32_t>(n_top));
+    }
+    {
+        TopRegions top = build_top(out.lnodes.data(), static_cast<uint32_t>(total), out.n_top, out.has_bvh && staged_top);
+        out.top = std::move(top.recs), out.portal_ret = std::move(top.ret), out.top_k = top.k;
+    }
+    if (out.has_bvh && host_streams) {
+        out.lstreams.resize(8 * total);
+        place_streams_on_host(out.lnodes.data(), static_cast<uint32_t>(total), out.n_top, out.portal_ret.data(), out.lstreams.data());
     }
     RT_PACK_MARK(6);
     out.bound.resize(total);

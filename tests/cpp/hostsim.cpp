@@ -697,32 +697,39 @@ extern "C" int hostsim_shaft_audit(const rt_scene_desc* desc, const rt_camera_de
 }
 
 // ---------------------------------------------------------------------------------------------
-// pack_scene's walk streams with the seven direction orders laid out on the HOST (what rt_scene_create makes on the GPU
-// must equal them byte for byte).  out may be null to ask for the size.
-extern "C" int hostsim_pack_streams(const rt_scene_desc* desc, void* out, size_t cap, size_t* bytes_out) {
+// pack_scene's walk streams as rt_scene_create keeps them on the device, laid out on the HOST (what the GPU makes must
+// equal them byte for byte): a scene with a hierarchy: the eight direction orders, the canonical stream, the eight top
+// regions (kTopK records each); any other scene: the canonical stream.  out may be null to ask for the size.
+extern "C" int hostsim_pack_streams(const rt_scene_desc* desc, int staged_top, void* out, size_t cap, size_t* bytes_out) {
     PackedScene ps;
     std::string err;
-    const int rc = pack_scene(desc, ps, err, /*host_streams=*/true);
+    const int rc = pack_scene(desc, ps, err, /*host_streams=*/true, staged_top != 0);
     if (rc != RT_OK) return rc;
-    const size_t bytes = ps.lnodes.size() * sizeof(LNode);
+    const size_t bytes = (ps.lstreams.size() + ps.lnodes.size() + (ps.has_bvh ? ps.top.size() : 0)) * sizeof(LNode);
     if (bytes_out) *bytes_out = bytes;
     if (out) {
         if (cap < bytes) return RT_ERR_CAPACITY;
-        std::memcpy(out, ps.lnodes.data(), bytes);
+        char* o = static_cast<char*>(out);
+        std::memcpy(o, ps.lstreams.data(), ps.lstreams.size() * sizeof(LNode));
+        o += ps.lstreams.size() * sizeof(LNode);
+        std::memcpy(o, ps.lnodes.data(), ps.lnodes.size() * sizeof(LNode));
+        o += ps.lnodes.size() * sizeof(LNode);
+        if (ps.has_bvh) std::memcpy(o, ps.top.data(), ps.top.size() * sizeof(LNode));
     }
     return RT_OK;
 }
 
-// The direction-ordered compact streams of rt_pack.h (lane-mode walks of rt_kernel.h): structure of all eight, and
-// a closest-hit query through the ray's own stream against the same query through the canonical record stream, on
-// random rays.  out[0] = structural errors, out[1] = rays whose two answers differ, out[2] = records looked at in
-// canonical order, out[3] = records looked at in the ray's own order (both summed over the rays), out[4] = n_items,
-// out[5] = rays that hit something.
-extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int n_rays, uint32_t seed, const float* box6, uint64_t* out,
+// The direction-ordered compact streams of rt_pack.h and their staged tops (lane-mode walks of rt_kernel.h): structure of
+// all eight, and a closest-hit query the way traverse_lane walks — from the top region of the ray's own order, through
+// the portals into that order's stream — against the same query through the canonical stream, on random rays.
+// out[0] = structural errors, out[1] = rays whose two answers differ, out[2] = records looked at in canonical order,
+// out[3] = records looked at in the ray's own order (both summed over the rays), out[4] = n_items, out[5] = rays that
+// hit something, out[6] = records of out[3] that were read from a top region, out[7] = records in use per top region.
+extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int staged_top, int n_rays, uint32_t seed, const float* box6, uint64_t* out,
                                           char* err_out, int err_cap) {
     PackedScene ps;
     std::string err;
-    const int rc = pack_scene(desc, ps, err);
+    const int rc = pack_scene(desc, ps, err, /*host_streams=*/true, staged_top != 0);
     if (rc != RT_OK) {
         if (err_out && err_cap > 0) std::snprintf(err_out, static_cast<size_t>(err_cap), "%s", err.c_str());
         return rc;
@@ -730,25 +737,41 @@ extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int n_rays,
     const uint32_t n = ps.n_items;
     const uint32_t streams = ps.has_bvh ? 8u : 1u;
     uint64_t bad = 0;
-    if (ps.lnodes.size() != static_cast<size_t>(streams) * std::max<size_t>(ps.recs.size(), 1)) bad++;
+    if (ps.lnodes.size() != std::max<size_t>(ps.recs.size(), 1)) bad++;
+    if (ps.has_bvh && ps.lstreams.size() != 8 * ps.lnodes.size()) bad++;
+    if (ps.top.size() != 8 * kTopK || ps.top_k > kTopK) bad++;
+    auto stream_of = [&](uint32_t k) { return ps.has_bvh ? ps.lstreams.data() + static_cast<size_t>(k) * n : ps.lnodes.data(); };
+    auto fetch = [&](uint32_t k, uint32_t i, bool& ok) {  // index space of rt_math.h: < n memory, n end, > n top region
+        ok = i < n || (i > n && i - n - 1u < ps.top_k);
+        if (!ok) return LNode{};
+        return i < n ? stream_of(k)[i] : ps.top[k * kTopK + (i - n - 1u)];
+    };
     for (uint32_t k = 0; k < streams && !bad; ++k) {
-        const LNode* st = ps.lnodes.data() + static_cast<size_t>(k) * n;
-        std::vector<uint8_t> seen(n, 0);
-        std::vector<uint32_t> ends;  // open subtrees
-        for (uint32_t i = 0; i < n; ++i) {
-            while (!ends.empty() && ends.back() == i) ends.pop_back();
-            const uint32_t type = st[i].ref >> kLRefShift, ref = st[i].ref & kLRefMask;
-            if (st[i].next <= i || st[i].next > n) bad++;
-            if (!ends.empty() && st[i].next > ends.back()) bad++;
-            if (type == REC_NODE) {
-                if (st[i].next > i + 1) ends.push_back(st[i].next);
-            } else {
-                if (st[i].next != i + 1 || ref >= n || seen[ref] || ps.recs[ref].type != type) bad++;
-                else seen[ref] = 1;
+        // entering everything: every primitive record exactly once, and the walk ends; entering nothing: it ends too
+        for (int enter = 1; enter >= 0 && !bad; --enter) {
+            std::vector<uint8_t> seen(n, 0);
+            uint32_t i = ps.top_k ? n + 1u : 0u;
+            uint64_t steps = 0;
+            while (i != n && !bad) {
+                bool ok;
+                const LNode nd = fetch(k, i, ok);
+                if (!ok || ++steps > 4ull * n + 64) {
+                    bad++;
+                    break;
+                }
+                const uint32_t type = nd.ref >> kLRefShift, ref = nd.ref & kLRefMask;
+                if (type == REC_NODE) i = enter ? i + 1u : nd.next;
+                else if (type == REC_PORTAL) i = enter ? ref : nd.next;
+                else {
+                    if (ref >= n || seen[ref] || ps.recs[ref].type != type) bad++;
+                    else seen[ref] = 1;
+                    i = nd.next;
+                }
             }
+            if (enter)
+                for (uint32_t r = 0; r < n; ++r)
+                    if (ps.recs[r].type != REC_NODE && !seen[r]) bad++;
         }
-        for (uint32_t i = 0; i < n; ++i)
-            if (ps.recs[i].type != REC_NODE && !seen[i]) bad++;
     }
     out[0] = bad, out[1] = out[2] = out[3] = out[5] = 0, out[4] = n;
     if (bad) return RT_OK;
@@ -757,18 +780,30 @@ extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int n_rays,
         state = state * 1664525u + 1013904223u;
         return static_cast<float>(state >> 8) * (1.0f / 16777216.0f);
     };
-    auto query = [&](const LNode* st, const Ray& ray, uint64_t& looked, uint32_t& prim_out, float& t_out) {
+    out[6] = 0, out[7] = ps.top_k;
+    // k < 0: the canonical stream from its first record; else order k from its top region (traverse_lane, rt_kernel.h)
+    auto query = [&](int k, const Ray& ray, uint64_t& looked, uint32_t& prim_out, float& t_out) {
         const V3 inv_d = inv_dir(ray.d);
         prim_out = kNoPrim, t_out = INFINITY;
-        for (uint32_t i = 0; i < n;) {
-            const LNode& nd = st[i];
+        uint32_t i = (k >= 0 && ps.top_k) ? n + 1u : 0u;
+        while (i != n) {
+            bool ok;
+            LNode nd;
+            if (k < 0) nd = ps.lnodes[i];
+            else nd = fetch(static_cast<uint32_t>(k), i, ok);
             ++looked;
+            if (k >= 0 && i > n) out[6]++;
             const bool in = bvh_node_hit(nd, ray.o, inv_d, 0.0f, t_out + tie_window(t_out));
-            if ((nd.ref >> kLRefShift) == REC_NODE) {
-                i = in ? i + 1 : nd.next;
+            const uint32_t type = nd.ref >> kLRefShift;
+            if (type == REC_NODE) {
+                i = in ? i + 1u : nd.next;
                 continue;
             }
-            ++i;
+            if (type == REC_PORTAL) {
+                i = in ? (nd.ref & kLRefMask) : nd.next;
+                continue;
+            }
+            i = nd.next;
             if (!in) continue;
             const uint32_t prim = nd.ref & kLRefMask;
             intersect_prim(ps.recs[prim], ps.extras.data(), ray, false, [&](int, float t, float, float) {
@@ -788,9 +823,9 @@ extern "C" int hostsim_lane_streams_check(const rt_scene_desc* desc, int n_rays,
         ray.self = kNoPrim, ray.q = v3(0, 0, 0), ray.dq = v3(0, 0, 0);
         uint32_t pa, pb;
         float ta, tb;
-        query(ps.lnodes.data(), ray, out[2], pa, ta);
+        query(-1, ray, out[2], pa, ta);
         const uint32_t oct = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
-        query(ps.lnodes.data() + static_cast<size_t>(streams == 8 ? oct : 0) * n, ray, out[3], pb, tb);
+        query(static_cast<int>(streams == 8 ? oct : 0), ray, out[3], pb, tb);
         if (pa != kNoPrim) out[5]++;
         // the two orders may settle a tie inside the tie window differently; anything else is an error
         if (pa != pb && !(pa != kNoPrim && pb != kNoPrim && ties_hit(ta, tb))) out[1]++;

@@ -111,16 +111,18 @@ def hostsim_render(example, options=None) -> np.ndarray:
     return out
 
 
-def hostsim_streams(scene_desc) -> np.ndarray:
-    """All eight walk streams of a scene laid out on the host by rt_pack.h ([8 * records, 8] uint32 words; one stream
-    for a scene without a hierarchy)."""
+def hostsim_streams(scene_desc, staged_top: bool = True) -> np.ndarray:
+    """The walk streams of a scene as rt_scene_create keeps them on the device, laid out on the host by rt_pack.h
+    ([records, 8] uint32 words): eight direction orders + canonical order + eight top regions of 16 records for a scene
+    with a hierarchy, the canonical order alone otherwise.  staged_top=False: no top regions picked (the product's
+    default: the regions are all zero and the streams have no portals)."""
     L = hostsim()
-    L.hostsim_pack_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.hostsim_pack_streams.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     n = C.c_size_t()
-    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), None, 0, C.byref(n))
+    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), int(staged_top), None, 0, C.byref(n))
     assert rc == 0, rc
     out = np.zeros((n.value // 32, 8), dtype=np.uint32)
-    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(n))
+    rc = L.hostsim_pack_streams(C.cast(scene_desc, C.c_void_p), int(staged_top), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(n))
     assert rc == 0, rc
     return out
 

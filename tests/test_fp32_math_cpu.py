@@ -142,7 +142,8 @@ def test_full_resolution_probes_cover_image():
     ("cover_image", (-6.0, -2.0, -8.0, 6.0, 6.0, 6.0)),
     ("obj_mesh", (-3.0, -1.0, -5.0, 3.0, 3.0, 3.0)),
 ])
-def test_direction_ordered_streams_answer_like_the_canonical_stream(name, box):
+@pytest.mark.parametrize("staged", [False, True])
+def test_direction_ordered_streams_answer_like_the_canonical_stream(name, box, staged):
     """rt_pack.h lays the device's hierarchy out once per sign pattern of a ray direction (lane-mode walks of
     rt_kernel.h).  All eight streams must hold every primitive record exactly once with properly nested skip links,
     and a closest-hit query through a ray's own stream must give the answer of the canonical stream (up to the
@@ -150,18 +151,23 @@ def test_direction_ordered_streams_answer_like_the_canonical_stream(name, box):
     import ctypes as C
     ex = ExampleScene(name, 64, 36)
     L = H.hostsim()
-    L.hostsim_lane_streams_check.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
-    out = (C.c_uint64 * 6)()
+    L.hostsim_lane_streams_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    out = (C.c_uint64 * 8)()
     err = C.create_string_buffer(256)
     b = (C.c_float * 6)(*box)
-    rc = L.hostsim_lane_streams_check(C.cast(ex.scene_desc, C.c_void_p), 20000, 7, b, out, err, 256)
+    rc = L.hostsim_lane_streams_check(C.cast(ex.scene_desc, C.c_void_p), int(staged), 20000, 7, b, out, err, 256)
     assert rc == 0, err.value
-    structural, differ, looked_canon, looked_own, n_items, hits = [int(v) for v in out]
+    structural, differ, looked_canon, looked_own, n_items, hits, from_top, top_k = [int(v) for v in out]
     assert structural == 0
+    if staged:  # the walks start in the staged top (rt_math.h kTopK; an experiment the product keeps switched off)
+        assert 3 <= top_k <= 16 and from_top > 0
+    else:
+        assert top_k == 0 and from_top == 0
     assert differ == 0, (differ, hits)
     assert hits > 1000
     assert looked_own <= looked_canon, (looked_own, looked_canon)
-    print(f"{name}: {n_items} records, per ray {looked_canon / 20000:.1f} records looked at in canonical order, {looked_own / 20000:.1f} in the ray's own")
+    print(f"{name}: {n_items} records, per ray {looked_canon / 20000:.1f} records looked at in canonical order, {looked_own / 20000:.1f} in the ray's own, "
+          f"{from_top / max(1, looked_own):.2f} of those in the staged top ({top_k} records)")
 
 
 def _stream_hash(n_triangles: int, threads: int) -> str:
@@ -188,21 +194,28 @@ def test_hierarchy_build_does_not_depend_on_the_number_of_threads():
 
 
 def test_streams_hold_the_split_axis_and_nest():
-    """Structure of the canonical stream the GPU derives the other seven from (lane_streams_kernel): a node's low ref bits
-    hold its split axis (3 = a pair of primitives), spans nest, a subtree over n primitives spans 2n - 1 records."""
+    """Structure of the canonical stream the GPU derives the direction orders from (lane_place, rt_math.h): a node's low
+    ref bits hold its split axis (3 = a pair of primitives) and the portal marks, spans nest, a subtree over n primitives
+    spans 2n - 1 records; every direction order holds the same primitive records once."""
     ex = ExampleScene("multiple_glass_and_metallic_spheres", 64, 36)
     st = H.hostsim_streams(ex.scene_desc)
-    n = st.shape[0] // 8
-    canon = st[:n]
+    n = (st.shape[0] - 8 * 16) // 9
+    canon = st[8 * n:9 * n]
     is_node = (canon[:, 7] >> 29) == 6  # REC_NODE
-    assert is_node.any() and ((canon[is_node, 7] & 0x1FFFFFFF) <= 3).all()
+    assert is_node.any()
     idx = np.arange(n)
     assert (canon[~is_node, 6] == idx[~is_node] + 1).all()
     spans = canon[is_node, 6] - idx[is_node]
     assert (spans % 2 == 1).all() and (spans >= 3).all()
     pairs = is_node & ((canon[:, 7] & 3) == 3)
     assert (canon[pairs, 6] - idx[pairs] == 3).all()
-    for o in range(1, 8):  # every stream holds the same primitive records once
+    portals = is_node & ((canon[:, 7] & 4) != 0)
+    ids = (canon[portals, 7] & 0x1FFFFFFF) >> 3
+    assert 2 <= portals.sum() <= 16 and np.array_equal(np.sort(ids), np.arange(portals.sum()))
+    for o in range(8):
         s_o = st[o * n:(o + 1) * n]
-        prim = (s_o[:, 7] >> 29) != 6
+        prim = (s_o[:, 7] >> 29) < 6
         assert np.array_equal(np.sort(s_o[prim, 7]), np.sort(canon[~is_node, 7]))
+        top = st[9 * n + 16 * o:9 * n + 16 * (o + 1)]
+        kinds = top[:, 7] >> 29
+        assert (kinds == 7).sum() == portals.sum()  # REC_PORTAL
