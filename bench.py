@@ -43,6 +43,9 @@ Rank 0 prints ONE JSON line.
   also      the other BASELINE configs a multi-GPU run is about (C4 and cover-image at 3840x2160), timed in
             the same run with the same partition and assembly.
   sustained back-to-back frames for >= 0.3 s after the timed steps.
+  preroll_frames  untimed frames rendered BEFORE the W warm-up steps (--settle seconds of them, default 0.25 s): the GPU's
+            clocks need a few hundred 0.15 ms frames to settle, and a short timed region straight after an idle period
+            measured the ramp, not the kernel.
   first_frame_kernel_ms  the kernel time of the FIRST frame of a fresh scene object: scenes with glass start the
             expensive tiles of a frame first once the previous frame has measured them; a single-shot
             render gets this number, the timed loop the steady state.
@@ -101,6 +104,7 @@ def parse_args():
     ap.add_argument("--f32-only", action="store_true", help="RT_FLAG_F32_ONLY: without the f64 chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the C4 / cover-image 4K frames")
+    ap.add_argument("--settle", type=float, default=0.25, help="seconds of untimed frames before the warm-up steps (clock settling); 0 = none")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -257,7 +261,7 @@ def one_shot_calls(ex: ExampleScene, device: int, opt: RtOptions) -> dict:
     return out
 
 
-def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmup: int, sustain_s: float) -> dict:
+def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmup: int, sustain_s: float, settle_s: float = 0.0) -> dict:
     """Times `steps` frames of one workload on this job's partition; returns rank 0's report."""
     args, rank, world, dist = job.args, job.rank, job.world, job.dist
     ex = ExampleScene(name, width, height)
@@ -371,6 +375,21 @@ def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmu
             mode = forced
         calibration = {k: (v / 5 * 1e3 if v < 1e29 else None) for k, v in took.items()}
 
+    # Pre-roll (untimed, before the W warm-up steps): a frame is 0.15 ms and the GPU's clocks take a few hundred of them
+    # to settle — a 20-step timed region straight after an idle period read 11 % slower than a 200-step one (round 2).
+    # Every rank runs the same number of frames (the count comes from an all-reduced time).
+    preroll = 0
+    if settle_s > 0:
+        job.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            frame(mode)
+        job.sync_all()
+        per_frame = job.max_over_ranks(time.perf_counter() - t0) / 5
+        preroll = int(min(5000, max(0, math.ceil(settle_s / max(per_frame, 1e-6)))))
+        for _ in range(preroll):
+            frame(mode)
+        job.sync_all()
     for _ in range(warmup):
         frame(mode)
     job.sync_all()
@@ -454,7 +473,7 @@ def run_workload(job: Job, name: str, width: int, height: int, steps: int, warmu
             "workload": f"examples/{name} at {width}x{height}, jitter={args.jitter} seed={args.seed}, RECURSION_DEPTH=5, "
                         f"{'FP32 only' if args.f32_only else 'f64 chain on'}",
             "frame_ms": ms, "kernel_ms": kernel_ms, "first_frame_kernel_ms": first_kernel_ms, "render_call_ms": render_call, "assembly": mode, "assembly_calibration_ms_per_frame": calibration,
-            "assembled_frame_equals_single_gpu_frame": verified, "sustained": sustained,
+            "assembled_frame_equals_single_gpu_frame": verified, "sustained": sustained, "preroll_frames": preroll,
             "rays_per_frame": total_rays, "rays_cast": rays_cast, "cast_share": rays_cast / max(1, total_rays),
             "rays_by_kind": total, "mrays_per_s": total_rays / (ms * 1e-3) / 1e6, "mrays_cast_per_s": rays_cast / (ms * 1e-3) / 1e6,
             "kernel": scene.kernel_name(ex.camera_desc, opt), "mine": mine, "n_lights": n_lights,
@@ -477,7 +496,7 @@ def main():
     world = job.world
     width, height = WORKLOADS[args.workload]
     width, height = args.width or width, args.height or height
-    head = run_workload(job, args.workload, width, height, args.steps, args.warmup, sustain_s=0.3)
+    head = run_workload(job, args.workload, width, height, args.steps, args.warmup, sustain_s=0.3, settle_s=args.settle)
 
     also = {}
     if not args.no_also:
@@ -533,6 +552,7 @@ def main():
             "first_frame_kernel_ms": head["first_frame_kernel_ms"],
             "render_call_ms": head["render_call_ms"],
             "sustained": head["sustained"],
+            "preroll_frames": head["preroll_frames"],
             "roofline": {
                 "bound": "valu_fp32", "achieved": hw["executed_tflops"], "peak": flopmodel.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": hw["frac"], "traffic": hw["traffic"],
