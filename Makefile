@@ -8,7 +8,11 @@ CXX      ?= g++
 ARCH     ?= gfx950
 LIBDIR   ?= raytracer_amd/_lib
 OBJDIR   ?= build/obj
-HIPCFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical
+# -memssa-check-limit: the scalar (s_load) fetches of the scene records need the compiler's proof that no store of the
+# kernel can clobber them, and that proof walks MemorySSA with a budget of 100 steps by default; one more LDS store in the
+# path loop and every record of the union walks came through vector loads (cover_image 1.33 -> 1.86 ms).  DESIGN.md §7.2.
+HIPCFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical \
+             -mllvm -memssa-check-limit=2000
 CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -Wall -Wextra -Wno-unused-parameter -ffp-contract=off
 CSRC     := raytracer_amd/csrc
 KHEADERS := $(CSRC)/rt_kernel.h $(CSRC)/rt_math.h $(CSRC)/rt_exact.h include/rt_amd.h

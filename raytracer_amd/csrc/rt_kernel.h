@@ -616,6 +616,53 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // competes for registers.)
     Ray64 r64[(EXACT && SPAWN) ? kStackCap + 1 : 1];
     uint32_t cur_slot = 0;
+    // ... except slot 0 in the kernels with the f64 chain and no area-light code: they run 4 waves a SIMD with 24 park rows
+    // and can afford 12 more (36 rows x 256 B x 16 waves = 147 KB a CU).  Every node whose child goes on in the lane writes
+    // slot 0 and every refined node reads its slot: in private memory that was most of C4's 10.8 GB of L2<->fabric traffic.
+#ifndef RT_R64_LDS
+#define RT_R64_LDS 1
+#endif
+    constexpr bool kR64Lds = EXACT && SPAWN && !AREA && RT_R64_LDS != 0;
+    __shared__ float s_park[(AREA ? 35 : (kR64Lds ? 36 : 24)) * kBlockThreads];
+    float* const park = s_park + threadIdx.x;
+    // (The LDS side goes through a pointer TYPED as LDS: with plain pointers the compiler folds "slot 0 ? LDS : private" into
+    // one access through a generic pointer — a flat store inside the path loop, after which it no longer trusts the scene
+    // tables to be unchanged and fetches every record of the union walks through vector loads: cover_image 1.33 -> 1.86 ms.)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) float LdsFloat;
+    LdsFloat* const park64 = (LdsFloat*)park;
+#else
+    float* const park64 = park;
+#endif
+    auto r64_store = [&](uint32_t slot, D3 o, D3 d) {
+        if (kR64Lds && slot == 0u) {
+            const double v[6] = {o.x, o.y, o.z, d.x, d.y, d.z};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v[k]));
+                park64[(24 + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b));
+                park64[(25 + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b >> 32));
+            }
+        } else {
+            r64[slot].o = o, r64[slot].d = d;
+        }
+    };
+    auto r64_load = [&](uint32_t slot) {
+        Ray64 r;
+        if (kR64Lds && slot == 0u) {
+            double v[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long b = static_cast<unsigned long long>(__float_as_uint(park64[(24 + 2 * k) * kBlockThreads])) |
+                                             (static_cast<unsigned long long>(__float_as_uint(park64[(25 + 2 * k) * kBlockThreads])) << 32);
+                v[k] = __longlong_as_double(static_cast<long long>(b));
+            }
+            r.o = d3(v[0], v[1], v[2]), r.d = d3(v[3], v[4], v[5]);
+        } else {
+            r = r64[slot];
+        }
+        return r;
+    };
     // EXACT: the FixRecords of this lane ("unsure shadow rays" above), until the wave's path loop is over;
     // pend[0].scratch[0] counts them (what does not fit keeps its FP32 count).  Private memory like the stack: indexed
     // dynamically, never in registers.
@@ -639,7 +686,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
             xcamera_ray(P.cam64, px, pgy, r.o, r.d);
         } else {
-            r = r64[cur_slot];
+            r = r64_load(cur_slot);
         }
         return r;
     };
@@ -647,8 +694,6 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // lane and, in the cooperative passes, from the owner's slots (an LDS broadcast)
     // slot 34: the lane's jitter key (constant for the whole kernel)
     constexpr bool kFix = EXACT && RT_NO_EMIT < 2;
-    __shared__ float s_park[(AREA ? 35 : 24) * kBlockThreads];
-    float* const park = s_park + threadIdx.x;
     if (AREA) park[34 * kBlockThreads] = __uint_as_float(pixel_key);
     if (kSteal) park[3 * kBlockThreads] = 0.0f, park[4 * kBlockThreads] = 0.0f, park[5 * kBlockThreads] = 0.0f;
     float* const pixel_sum = s_park + (threadIdx.x & ~63u);  // + (3 + channel) * kBlockThreads + pix
@@ -880,11 +925,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 tir64 = !xrefract(xh, x1, x2, rd);
                 refr = !tir64;
             }
-            if (refr) {
-                Ray64& slot = r64[(refl && sp < kStackCap) ? 1 + sp : 0];
-                slot.o = xh.under, slot.d = rd;
-            }
-            if (refl) r64[0].o = xh.over, r64[0].d = xh.reflectv;
+            if (refr) r64_store((refl && sp < kStackCap) ? 1u + static_cast<uint32_t>(sp) : 0u, xh.under, rd);
+            if (refl) r64_store(0u, xh.over, xh.reflectv);
             if (STATS) c_refined++;
           }
         }
@@ -951,7 +993,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         r.over_mid[0] = refined ? __uint_as_float(pend[0].scratch[1]) : 0.0f, r.over_mid[1] = refined ? __uint_as_float(pend[0].scratch[2]) : 0.0f;
                         r.over_mid[2] = refined ? __uint_as_float(pend[0].scratch[3]) : 0.0f;
                         if (!refined && node != 0u) {  // (its ray is still where it was: only a refined node writes its children's rays early;
-                            const Ray64 rr = r64[cur_slot];  //  the camera ray is worked out from the pixel when the record leaves)
+                            const Ray64 rr = r64_load(cur_slot);  //  the camera ray is worked out from the pixel when the record leaves)
                             r.ray[0] = rr.o.x, r.ray[1] = rr.o.y, r.ray[2] = rr.o.z, r.ray[3] = rr.d.x, r.ray[4] = rr.d.y, r.ray[5] = rr.d.z;
                         }
                         pend[0].scratch[0] = n + 1u;
@@ -1367,9 +1409,13 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         if (EXACT && !(RT_XEXP & 32) && has_hit && want_refr) {
             // the refraction ray's f64 copy: written by the refined node above, else (no f64 hit) the chain
             // restarts from the FP32 ray
-            Ray64& slot = r64[push ? 1 + sp : 0];
-            if (chain) under = to_v3(slot.o), rdir = to_v3(slot.d);
-            else slot.o = to_d3(under), slot.d = to_d3(rdir);
+            const uint32_t slot = push ? 1u + static_cast<uint32_t>(sp) : 0u;
+            if (chain) {
+                const Ray64 kept = r64_load(slot);
+                under = to_v3(kept.o), rdir = to_v3(kept.d);
+            } else {
+                r64_store(slot, to_d3(under), to_d3(rdir));
+            }
         }
 
         if (push) {
@@ -1384,8 +1430,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const V3 din = neg(eye);                     // the incoming direction, back from its parked negation
             cur.d = din - nrm * (2.0f * dot(din, nrm));  // tuple.rs:121-123
             if (EXACT && !(RT_XEXP & 32)) {
-                if (chain) cur.d = to_v3(r64[0].d);
-                else r64[0].o = to_d3(cur.o), r64[0].d = to_d3(cur.d);
+                if (chain) cur.d = to_v3(r64_load(0u).d);
+                else r64_store(0u, to_d3(cur.o), to_d3(cur.d));
                 cur_slot = 0;
             }
             cur.self = hit_prim, cur.q = hq, cur.dq = hdq;
@@ -1469,7 +1515,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                                                          (static_cast<unsigned long long>(__float_as_uint(get(20 + 2 * k, r_idle))) << 32);
                             d6[k] = __longlong_as_double(static_cast<long long>(b));
                         }
-                        r64[0].o = d3(d6[0], d6[1], d6[2]), r64[0].d = d3(d6[3], d6[4], d6[5]);
+                        r64_store(0u, d3(d6[0], d6[1], d6[2]), d3(d6[3], d6[4], d6[5]));
                         cur_slot = 0;
                     }
                     if (AREA) park[34 * kBlockThreads] = key;
@@ -1512,6 +1558,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             D3 over64 = d3(static_cast<double>(fl(9)) + static_cast<double>(fl(12)), static_cast<double>(fl(10)) + static_cast<double>(fl(13)),
                            static_cast<double>(fl(11)) + static_cast<double>(fl(14)));
             bool ok = li < sc.n_lights && self_prim < sc.n_items;
+#ifdef RT_FIX_STUB  // experiment: the second count without its arithmetic (what the block's mere presence costs)
+            ok = false;
+#endif
             if (ok && !was_refined) {  // the node's f64 hit, worked out again from its f64 ray (intersection.rs:40-69)
                 D3 ro = d3(db(20), db(22), db(24)), rd = d3(db(26), db(28), db(30));
                 if (at_node == 0u) {

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 
 def one(group):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", f"-DRT_KGROUP={group}",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-mllvm", "-memssa-check-limit=2000", f"-DRT_KGROUP={group}",
            "-Rpass-analysis=kernel-resource-usage", "-c", "raytracer_amd/csrc/rt_kernels.hip", "-o", f"/tmp/rt_res_{group}.o"]
     return subprocess.run(cmd + sys.argv[1:], capture_output=True, text=True).stderr
 
