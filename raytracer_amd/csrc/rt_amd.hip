@@ -339,7 +339,14 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     std::string err;
     const auto t_start = std::chrono::steady_clock::now();
     const bool staged_top = RT_LDS_TOP != 0 && !std::getenv("RT_AMD_NO_TOP");  // (N1, rt_kernel.h: an experiment; the variable: its A/B timings)
-    int rc = pack_scene(desc, ps, err, /*host_streams=*/false, staged_top);
+    int rc = RT_OK;
+    try {  // (the build runs on host threads and sizes tables of hundreds of megabytes: nothing may unwind across the C ABI)
+        rc = pack_scene(desc, ps, err, /*host_streams=*/false, staged_top);
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_CAPACITY, "out of host memory while building the scene tables");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_BAD_ARGUMENT, std::string("scene build failed: ") + e.what());
+    }
     if (rc != RT_OK) return fail(rc, err);
     const auto t_packed = std::chrono::steady_clock::now();
     int ndev = 0;

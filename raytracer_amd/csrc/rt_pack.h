@@ -884,9 +884,13 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
     RT_PACK_MARK(7);
     if (out.has_f64) {  // record i of the stream is the primitive of item order[i]
         out.xprims.resize(out.recs.size());
+        if (out.n_items == 0) out.xprims[0] = XPrim{};
         parallel_chunks(out.n_items, 1u << 14, [&](unsigned, size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
-                if (out.recs[i].type == REC_NODE) continue;
+                if (out.recs[i].type == REC_NODE) {
+                    out.xprims[i] = XPrim{};  // (never read; the table is not zeroed when it is sized)
+                    continue;
+                }
                 const uint32_t ref = d->item_ref[out.order[i]];
                 std::memcpy(out.xprims[i].inv, d->prim_inv64 + 12 * static_cast<size_t>(ref), sizeof(out.xprims[i].inv));
             }
