@@ -664,7 +664,7 @@ inline void place_streams_on_host(const LNode* canon, uint32_t n, uint32_t n_top
     });
 }
 
-#ifdef RT_PACK_TIMING  // (scratch/pack_time.cpp: where the time of a large scene goes)
+#ifdef RT_PACK_TIMING  // (scripts/pack_time.cpp: where the time of a large scene goes)
 #include <chrono>
 inline double g_pack_marks[16];
 #define RT_PACK_MARK(i) g_pack_marks[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()
