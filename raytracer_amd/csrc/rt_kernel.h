@@ -675,6 +675,19 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     // ... and, in three more words of pend[0] no record uses (scratch[1..3]), what the f64 over point of the
     // current node holds beyond its FP32 value if the node was refined (private as well: three LDS rows for it cost
     // cover_image_area a wave per CU, 2.0 -> 2.15 ms)
+    // The f64 camera (30 dwords of kernel arguments) and the pointers of the f64 tables are read WHERE they are used —
+    // refined nodes, second counts — through an address the compiler cannot move out of the path loop (n_rounds never reaches
+    // 2^31, which it cannot know): read as plain `P.cam64`, `sc.xprims` their loads were hoisted to the kernel's entry, and
+    // with no scalar registers to hold them they went straight into lanes of a spill VGPR (v_writelane at entry, v_readlane
+    // at every use; C2 0.174 -> 0.165 ms for the camera alone).
+#ifndef RT_LATE_CAM64
+#define RT_LATE_CAM64 1
+#endif
+    auto args_here = [&]() -> const KParams& {  // the kernel arguments, read where the reader stands
+        if (!RT_LATE_CAM64) return P;
+        return *reinterpret_cast<const KParams*>(reinterpret_cast<const char*>(&P) + (n_rounds >> 31));
+    };
+    auto cam64_here = [&]() -> const XCamera& { return args_here().cam64; };
     auto cur64 = [&]() {
         Ray64 r;
         if (node == 0u) {
@@ -683,8 +696,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             // scene tables as unclobbered, and every record of the walks comes through a VECTOR load instead of
             // a scalar one — C4 9 -> 20 ms, profiles/r02_exact_chain_smem_regression.txt.)
             uint32_t px, pyl, pgy;
-            pixel_of_lane(P, kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
-            xcamera_ray(P.cam64, px, pgy, r.o, r.d);
+            pixel_of_lane(args_here(), kOrder, wave, threadIdx.x & 63u, px, pyl, pgy);
+            xcamera_ray(cam64_here(), px, pgy, r.o, r.d);
         } else {
             r = r64_load(cur_slot);
         }
@@ -774,13 +787,13 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 const bool a_first = b == kNoPrim || (a != kNoPrim && (TREE ? sc.order[a] < sc.order[b] : a < b));
                 const uint32_t first = a_first ? a : b, second = a_first ? b : a;  // first is never kNoPrim here
                 const DPrim pa = sc.recs[first];
-                const XHits ha = xintersect<EXOTIC>(pa.type, sc.xprims[first].inv, sc.xextras[pa.extra].f, r.o, r.d);
+                const XHits ha = xintersect<EXOTIC>(pa.type, args_here().sc.xprims[first].inv, args_here().sc.xextras[pa.extra].f, r.o, r.d);
                 XHits hb = ha;
                 uint32_t type_b = REC_NODE;
                 if (second != kNoPrim) {  // rare: a second candidate
                     const DPrim pb = sc.recs[second];
                     type_b = pb.type;
-                    hb = xintersect<EXOTIC>(pb.type, sc.xprims[second].inv, sc.xextras[pb.extra].f, r.o, r.d);
+                    hb = xintersect<EXOTIC>(pb.type, args_here().sc.xprims[second].inv, args_here().sc.xextras[pb.extra].f, r.o, r.d);
                 }
                 uint32_t pr = kNoPrim;
                 if (xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64)) {
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 if (wave_any(amb_prim != kNoPrim) && amb_prim != kNoPrim) {
                     const Ray64 r = cur64();
                     const DPrim pa = sc.recs[amb_prim];
-                    const XHits hx = xintersect<EXOTIC>(pa.type, sc.xprims[amb_prim].inv, sc.xextras[pa.extra].f, r.o, r.d);
+                    const XHits hx = xintersect<EXOTIC>(pa.type, args_here().sc.xprims[amb_prim].inv, args_here().sc.xextras[pa.extra].f, r.o, r.d);
                     cs.add(xplace(hx, t64, hit_t), false, TREE ? sc.order[amb_prim] : amb_prim, pa.ior, ord_hit, hit_t, amb_prim);
                 }
             }
@@ -885,15 +898,15 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         if (EXACT && !(RT_XEXP & 2) && has_hit && (refined || late)) {
             const DPrim p = sc.recs[hit_prim];
             const DMaterial m = sc.mats[mi];
-            const double* xinv = sc.xprims[hit_prim].inv;
+            const double* xinv = args_here().sc.xprims[hit_prim].inv;
             const Ray64 r = cur64();
             if (!refined) {  // (late: the same primitive's f64 hit; if f64 finds none the FP32 hit stands)
-                const XHits ha = xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d);
+                const XHits ha = xintersect<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, r.o, r.d);
                 uint32_t pr = kNoPrim;
                 refined = xselect<EXOTIC>(ha, hit_prim, p.type, ha, kNoPrim, REC_NODE, false, t64, pr, u64, v64);
             }
           if (refined) {
-            const XHit xh = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
+            const XHit xh = xprepare<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
             qedge = xh.qedge;
             if constexpr (kFix && (RT_FIX_PARTS & 1)) {  // (what the f64 over point holds beyond its FP32 value: 48 of its 53 bits travel to the fix kernel)
@@ -909,7 +922,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const DPattern pat = sc.pats[m.pattern];
             if (!(RT_XEXP & 4) && pat.type != PAT_SOLID) {
                 double frac;
-                const bool is_a = xpattern_is_a(pat.type, xinv, sc.xpats[m.pattern].inv, xh.over, frac);
+                const bool is_a = xpattern_is_a(pat.type, xinv, args_here().sc.xpats[m.pattern].inv, xh.over, frac);
                 const V3 ca = v3(pat.a[0], pat.a[1], pat.a[2]), cb = v3(pat.b[0], pat.b[1], pat.b[2]);
                 pc = pat.type == PAT_GRADIENT ? ca + (cb - ca) * static_cast<float>(frac) : (is_a ? ca : cb);
             }
@@ -920,8 +933,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             D3 rd = d3(0.0, 0.0, 0.0);
             if ((RT_XEXP & 8) && refr) rd = to_d3(v3(0.1f, 0.2f, 0.3f));
             if (!(RT_XEXP & 8) && refr) {  // world.rs:109-130 with the f64 indices of the records the container pass named
-                const double x1 = n1_prim == kNoPrim ? 1.0 : sc.xior[sc.recs[n1_prim].material];
-                const double x2 = n2_prim == kNoPrim ? 1.0 : sc.xior[sc.recs[n2_prim].material];
+                const double x1 = n1_prim == kNoPrim ? 1.0 : args_here().sc.xior[sc.recs[n1_prim].material];
+                const double x2 = n2_prim == kNoPrim ? 1.0 : args_here().sc.xior[sc.recs[n2_prim].material];
                 tir64 = !xrefract(xh, x1, x2, rd);
                 refr = !tir64;
             }
@@ -1212,7 +1225,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     if (STATS && (dark || open || umbra)) c_shadow += cells;
                     need &= ~__ballot(dark || open || umbra);
                 }
-                if (P.tile_cost) n_visibility += static_cast<uint32_t>(__popcll(need)) * chunks;
+                n_visibility += static_cast<uint32_t>(__popcll(need)) * chunks;  // (counted whether or not a cost table asks: no pointer to keep)
                 [[maybe_unused]] const unsigned long long cast_mask = need;  // the lanes whose point casts rays towards this light
 
                 if (RT_EXP & 1024) need = 0;
@@ -1565,21 +1578,21 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 D3 ro = d3(db(20), db(22), db(24)), rd = d3(db(26), db(28), db(30));
                 if (at_node == 0u) {
                     uint32_t px, pyl, pgy;
-                    pixel_of_lane(P, kOrder, wave, pl, px, pyl, pgy);
-                    xcamera_ray(P.cam64, px, pgy, ro, rd);
+                    pixel_of_lane(args_here(), kOrder, wave, pl, px, pyl, pgy);
+                    xcamera_ray(cam64_here(), px, pgy, ro, rd);
                 }
                 const DPrim p = sc.recs[self_prim];
-                const double* xinv = sc.xprims[self_prim].inv;
-                const XHits ha = xintersect<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, ro, rd);
+                const double* xinv = args_here().sc.xprims[self_prim].inv;
+                const XHits ha = xintersect<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, ro, rd);
                 double ft = 0.0, fu = 0.0, fv = 0.0;
                 uint32_t pr = kNoPrim;
                 ok = xselect<EXOTIC>(ha, self_prim, p.type, ha, kNoPrim, REC_NODE, false, ft, pr, fu, fv);
-                if (ok) over64 = xprepare<EXOTIC>(p.type, xinv, sc.xextras[p.extra].f, ro, rd, ft, fu, fv).over;
+                if (ok) over64 = xprepare<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, ro, rd, ft, fu, fv).over;
             }
             float delta = 0.0f;
             if (ok) {
                 const DLight l = sc.lights[li];
-                const XLight xl = sc.xlights[li];
+                const XLight xl = args_here().sc.xlights[li];
                 const uint32_t cells = l.usteps * l.vsteps;
                 const V3 o = to_v3(over64);
                 uint32_t lit = 0;
@@ -1605,7 +1618,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         unocc = true;
                         if (dist2 > 0.0f) {  // (a null vector is lit, world.rs:77-81: xoccludes decides that in f64)
                             const float inv_dist = rsq_f(dist2);
-                            unocc = !fix_occluded<EXOTIC>(sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
+                            unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
                         }
                     }
                     lit += static_cast<uint32_t>(__popcll(wave_ballot(unocc)));
@@ -1632,16 +1645,18 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         uint32_t lane_again = threadIdx.x & 63u;
         asm volatile("" : "+v"(lane_again));
         uint32_t ox, oyl, ogy;
-        if (pixel_of_lane(P, kOrder, wave, lane_again, ox, oyl, ogy)) {
-            float* o = P.out + (static_cast<size_t>(P.global_rows ? ogy : oyl) * P.cam.hsize + ox) * 3u;
+        const KParams& PE = args_here();  // (the tiling and the camera's size, read again: not kept across the path loop)
+        if (pixel_of_lane(PE, kOrder, wave, lane_again, ox, oyl, ogy)) {
+            float* o = PE.out + (static_cast<size_t>(PE.global_rows ? ogy : oyl) * PE.cam.hsize + ox) * 3u;
             if (kSteal) acc = v3(park[3 * kBlockThreads], park[4 * kBlockThreads], park[5 * kBlockThreads]);
             o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
         }
     }
-    if (P.tile_cost) {
+    if (args_here().tile_cost) {
+        const KParams& PE = args_here();
         uint32_t tx, tyl, tgy;
-        pixel_of_lane(P, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
-        if (lane == 0) P.tile_cost[(tyl >> 3) * P.tiles_x + (tx >> 3)] = 10u * n_rounds + n_visibility;  // (a round ~ ten visibility passes)
+        pixel_of_lane(PE, kOrder, wave, 0u, tx, tyl, tgy);  // lane 0 = the tile's top-left pixel
+        if (lane == 0) PE.tile_cost[(tyl >> 3) * PE.tiles_x + (tx >> 3)] = 10u * n_rounds + n_visibility;  // (a round ~ ten visibility passes)
     }
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
