@@ -520,6 +520,12 @@ constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool 
 #define RT_MIN_BLOCKS_NOSPAWN 4
 #endif
     if (AREA && !TREE && !EXOTIC && !SPAWN) return RT_MIN_BLOCKS_NOSPAWN;
+    // the area-light kernels of plain hierarchies with the f64 chain: 3 waves and 168 VGPRs (3 spilled) beat 4 waves and 128
+    // (97 spilled) since the kernel arguments stopped taking spill lanes: cover_image_area 2.14 -> 2.05 ms
+#ifndef RT_MIN_BLOCKS_TREE_AREA_X
+#define RT_MIN_BLOCKS_TREE_AREA_X 3
+#endif
+    if (AREA && TREE && !EXOTIC && EXACT) return RT_MIN_BLOCKS_TREE_AREA_X;
     return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > RT_MIN_BLOCKS_FLAT_AREA ? RT_MIN_BLOCKS_FLAT_AREA : RT_MIN_BLOCKS);
 }
 // EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
@@ -622,8 +628,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #ifndef RT_R64_LDS
 #define RT_R64_LDS 1
 #endif
-    constexpr bool kR64Lds = EXACT && SPAWN && !AREA && RT_R64_LDS != 0;
-    __shared__ float s_park[(AREA ? 35 : (kR64Lds ? 36 : 24)) * kBlockThreads];
+    // (Not the area-light kernels, although those at 3 waves a SIMD have the room — 47 rows x 256 B x 12 waves = 141 KB:
+    // cover_image_area 2.05 -> 2.23 ms with it, 180 instead of 101 spilled SGPRs.)
+    constexpr bool kR64Lds = EXACT && SPAWN && RT_R64_LDS != 0 && !AREA;
+    constexpr int kR64Row = AREA ? 35 : 24;
+    __shared__ float s_park[(kR64Row + (kR64Lds ? 12 : 0)) * kBlockThreads];
     float* const park = s_park + threadIdx.x;
     // (The LDS side goes through a pointer TYPED as LDS: with plain pointers the compiler folds "slot 0 ? LDS : private" into
     // one access through a generic pointer — a flat store inside the path loop, after which it no longer trusts the scene
@@ -640,8 +649,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v[k]));
-                park64[(24 + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b));
-                park64[(25 + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b >> 32));
+                park64[(kR64Row + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b));
+                park64[(kR64Row + 1 + 2 * k) * kBlockThreads] = __uint_as_float(static_cast<uint32_t>(b >> 32));
             }
         } else {
             r64[slot].o = o, r64[slot].d = d;
@@ -653,8 +662,8 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             double v[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const unsigned long long b = static_cast<unsigned long long>(__float_as_uint(park64[(24 + 2 * k) * kBlockThreads])) |
-                                             (static_cast<unsigned long long>(__float_as_uint(park64[(25 + 2 * k) * kBlockThreads])) << 32);
+                const unsigned long long b = static_cast<unsigned long long>(__float_as_uint(park64[(kR64Row + 2 * k) * kBlockThreads])) |
+                                             (static_cast<unsigned long long>(__float_as_uint(park64[(kR64Row + 1 + 2 * k) * kBlockThreads])) << 32);
                 v[k] = __longlong_as_double(static_cast<long long>(b));
             }
             r.o = d3(v[0], v[1], v[2]), r.d = d3(v[3], v[4], v[5]);
