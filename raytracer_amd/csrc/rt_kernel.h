@@ -526,6 +526,9 @@ constexpr int min_blocks_of(bool EXOTIC, bool TREE, bool AREA, bool EXACT, bool 
 #define RT_MIN_BLOCKS_TREE_AREA_X 3
 #endif
     if (AREA && TREE && !EXOTIC && EXACT) return RT_MIN_BLOCKS_TREE_AREA_X;
+    // the FP32-only flat area-light kernels with path code: a fourth wave pays there (C3 with RT_FLAG_F32_ONLY 0.379 -> 0.346 ms;
+    // the same kernels WITH the f64 chain lose to it: C1 0.139 -> 0.150, profiles/r03_occupancy.txt)
+    if (AREA && !TREE && !EXOTIC && !EXACT && SPAWN) return 4;
     return !AREA ? (EXACT ? RT_MIN_BLOCKS_PLAIN_X : RT_MIN_BLOCKS_PLAIN) : ((!TREE || EXOTIC) && RT_MIN_BLOCKS > RT_MIN_BLOCKS_FLAT_AREA ? RT_MIN_BLOCKS_FLAT_AREA : RT_MIN_BLOCKS);
 }
 // EXACT = the scene and the camera carry the caller's f64 tables: every path ray is carried a second time
