@@ -22,6 +22,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -288,8 +289,15 @@ inline unsigned parallel_chunks(size_t n, size_t grain, F&& fn) {
     }
     std::vector<std::thread> th;
     th.reserve(chunks - 1);
-    for (size_t c = 1; c < chunks; ++c) th.emplace_back([&fn, c, n, chunks] { fn(static_cast<unsigned>(c), c * n / chunks, (c + 1) * n / chunks); });
+    size_t started = 1;  // chunk 0 is the caller's
+    try {
+        for (; started < chunks; ++started)
+            th.emplace_back([&fn, c = started, n, chunks] { fn(static_cast<unsigned>(c), c * n / chunks, (c + 1) * n / chunks); });
+    } catch (const std::system_error&) {
+        // no more threads to be had: the caller takes the chunks that got none
+    }
     fn(0u, size_t{0}, n / chunks);
+    for (size_t c = started; c < chunks; ++c) fn(static_cast<unsigned>(c), c * n / chunks, (c + 1) * n / chunks);
     for (auto& t : th) t.join();
     return static_cast<unsigned>(chunks);
 }
@@ -570,7 +578,11 @@ struct BvhBuild {
         };
         const unsigned n_threads = buf[0].size() > kSpawn ? pack_threads() : 1u;
         std::vector<std::thread> th;
-        for (unsigned i = 1; i < n_threads; ++i) th.emplace_back(worker);
+        try {
+            for (unsigned i = 1; i < n_threads; ++i) th.emplace_back(worker);
+        } catch (const std::system_error&) {
+            // fewer workers than asked for: the pool still drains (this thread is one of them)
+        }
         worker();
         for (auto& t : th) t.join();
     }
