@@ -68,6 +68,8 @@ pub struct rt_scene_desc {
     pub pat_inv64: *const f64,
     // optional: position (area: corner), uvec, vvec of every light in f64, nine a light (null: the f32 values)
     pub light_geom64: *const f64,
+    // optional: the Groups' boxes in f64, min then max, six a node (null: node_min / node_max)
+    pub node_box64: *const f64,
 }
 
 #[repr(C)]

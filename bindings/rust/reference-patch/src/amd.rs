@@ -67,6 +67,7 @@ pub(crate) struct FlatScene {
     mat_ior64: Vec<f64>,
     pat_inv64: Vec<f64>,
     light_geom64: Vec<f64>, // position (area: corner), uvec, vvec: nine a light
+    node_box64: Vec<f64>,   // a Group's box, min then max: six a node
 }
 
 /// First three rows of an affine 4x4, row-major, f64 -> f32 (rounded once).
@@ -158,6 +159,7 @@ impl FlatScene {
             let node = (self.node_min.len() / 3) as u32;
             self.node_min.extend_from_slice(&[bb.min.0.x as f32, bb.min.0.y as f32, bb.min.0.z as f32]);
             self.node_max.extend_from_slice(&[bb.max.0.x as f32, bb.max.0.y as f32, bb.max.0.z as f32]);
+            self.node_box64.extend_from_slice(&[bb.min.0.x, bb.min.0.y, bb.min.0.z, bb.max.0.x, bb.max.0.y, bb.max.0.z]);
             let at = self.item_ref.len();
             self.item_ref.push(sys::RT_ITEM_NODE | node);
             self.item_next.push(0);
@@ -269,6 +271,7 @@ impl FlatScene {
             mat_ior64: self.mat_ior64.as_ptr(),
             pat_inv64: self.pat_inv64.as_ptr(),
             light_geom64: self.light_geom64.as_ptr(),
+            node_box64: self.node_box64.as_ptr(),
         }
     }
 }

@@ -445,6 +445,7 @@ struct FlatScene {
     std::vector<uint32_t> prim_material, item_ref, item_next, mat_pattern, light_usteps, light_vsteps;
     std::vector<double> prim_inv64, prim_param64, mat_ior64, pat_inv64;  // the f64 values themselves (rt_exact.h)
     std::vector<double> light_geom64;                                    // position (area: corner), uvec, vvec: nine a light
+    std::vector<double> node_box64;                                      // a Group's box, min then max: six a node
 
     rt_scene_desc desc() const {
         rt_scene_desc d{};
@@ -468,6 +469,7 @@ struct FlatScene {
         d.prim_inv64 = prim_inv64.data(), d.prim_param64 = prim_param64.data();
         d.mat_ior64 = mat_ior64.data(), d.pat_inv64 = pat_inv64.data();
         d.light_geom64 = light_geom64.data();
+        d.node_box64 = node_box64.data();
         return d;
     }
 };
@@ -540,6 +542,7 @@ struct Flattener {
             uint32_t node = static_cast<uint32_t>(out.node_min.size() / 3);
             push3(out.node_min, bb.min.x, bb.min.y, bb.min.z);
             push3(out.node_max, bb.max.x, bb.max.y, bb.max.z);
+            for (double v : {bb.min.x, bb.min.y, bb.min.z, bb.max.x, bb.max.y, bb.max.z}) out.node_box64.push_back(v);
             size_t item = out.item_ref.size();
             out.item_ref.push_back(node | RT_ITEM_NODE);
             out.item_next.push_back(0);

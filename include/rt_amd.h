@@ -121,6 +121,10 @@ typedef struct rt_scene_desc {
      * cannot settle (a ray grazing an occluder, a point within 1e-4 of another surface) are decided from the
      * f64 over point towards the f64 light position (world.rs:73-92).  NULL: the f32 values are widened. */
     const double* light_geom64;    /* [n_lights][9]                                                   */
+    /* Optional (ABI 3), used with the four tables above: the Groups' boxes in the caller's f64, min then max.  A
+     * ray that clips a Group's box within FP32 reach of an edge is then let in or not by the reference's own test
+     * (group.rs:107, bounding_box.rs:81-84: tmin < tmax in f64).  NULL: node_min / node_max are widened. */
+    const double* node_box64;      /* [n_nodes][6]                                                    */
 } rt_scene_desc;
 
 /* Camera, camera.rs:64-73 after Camera::try_from (camera.rs:95-136). */

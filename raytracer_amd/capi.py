@@ -33,7 +33,7 @@ class RtSceneDesc(C.Structure):
         ("light_uvec", C.c_void_p), ("light_vvec", C.c_void_p), ("light_usteps", C.c_void_p),
         ("light_vsteps", C.c_void_p), ("light_color", C.c_void_p),
         ("prim_inv64", C.c_void_p), ("prim_param64", C.c_void_p), ("mat_ior64", C.c_void_p), ("pat_inv64", C.c_void_p),
-        ("light_geom64", C.c_void_p),
+        ("light_geom64", C.c_void_p), ("node_box64", C.c_void_p),
     ]
 
 

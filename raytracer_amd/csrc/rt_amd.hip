@@ -400,6 +400,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** scene_out)
     if (rc == RT_OK) rc = upload(ps.xior, &s->k.xior, s->owned);
     if (rc == RT_OK) rc = upload(ps.xpats, &s->k.xpats, s->owned);
     if (rc == RT_OK) rc = upload(ps.xlights, &s->k.xlights, s->owned);
+    if (rc == RT_OK) rc = upload(ps.xgates, &s->k.xgates, s->owned);
     s->has_f64 = ps.has_f64;
     s->k.n_items = ps.n_items;
     s->k.has_gates = ps.has_gates, s->k.has_bvh = ps.has_bvh;

@@ -141,6 +141,12 @@ RT_HD void xcaps(D3 o, D3 d, double ymin, double ymax, bool closed, XHits& h) { 
     t = (ymax - o.y) / d.y;
     if (xcheck_cap(o, d, t)) h.t[3] = t;
 }
+RT_HD XHits xabsent() {
+    XHits h;
+    h.u = 0.0, h.v = 0.0;
+    h.t[0] = h.t[1] = h.t[2] = h.t[3] = kAbsent;
+    return h;
+}
 // EXOTIC = false compiles the cylinder / triangle code out (rt_math.h intersect_prim does the same).
 template <bool EXOTIC = true>
 RT_HD XHits xintersect(uint32_t type, const double* inv, const double* e, D3 ro, D3 rd) {
@@ -319,7 +325,7 @@ struct XHit {
     D3 point, normal, eye, reflectv, over, under;
     D3 qobj;    // the hit point in object space; the coordinate a face / cap / plane fixes is set exactly
     int qround;  // what is left for FP32 (xsnap_q): 1 = scale onto the unit sphere, 2 = x, z onto the unit circle
-    bool qedge;  // a cube's point within 1e-5 of an edge that got the NEIGHBOURING face's normal (below): not snapped
+    bool qedge;  // a cube's point within 1e-5 of an edge that got the NEIGHBOURING face's normal, a cylinder's wall point that got an end's (below): not snapped
     bool inside;
 };
 template <bool EXOTIC = true>
@@ -368,9 +374,18 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
         case PRIM_CYLINDER: {  // cylinder.rs:172-184
             if (!EXOTIC) break;
             const double dist = p.x * p.x + p.z * p.z;
-            if (dist < 1.0 && xge(p.y, e[1] - kEpsD)) nobj = d3(0.0, 1.0, 0.0), h.qobj.y = e[1];
-            else if (dist < 1.0 && xle(p.y, e[0] + kEpsD)) nobj = d3(0.0, -1.0, 0.0), h.qobj.y = e[0];
+            // A WALL point within 1e-5 of an end gets that end's normal whenever its x^2 + z^2 happens to round below 1
+            // (shapes_zoo, pixel (1424, 727): the open cylinder's wall 8e-6 above its lower end).  The over point then
+            // still stands on the wall, and whether the rays that leave it meet the wall again at t ~ 1e-16 is the
+            // reference's own rounding noise: qedge, as for the cube; the point keeps its height and is a wall point.
+            const bool on_wall = fabs(dist - 1.0) <= 1e-9;
+            if (dist < 1.0 && xge(p.y, e[1] - kEpsD)) nobj = d3(0.0, 1.0, 0.0);
+            else if (dist < 1.0 && xle(p.y, e[0] + kEpsD)) nobj = d3(0.0, -1.0, 0.0);
             else nobj = d3(p.x, 0.0, p.z), h.qround = 2;
+            if (h.qround != 2) {
+                if (on_wall) h.qedge = true, h.qround = 2;
+                else h.qobj.y = nobj.y > 0.0 ? e[1] : e[0];
+            }
             break;
         }
         case PRIM_TRIANGLE:  // triangle.rs:135-137
@@ -460,6 +475,30 @@ RT_HD bool xoccludes(uint32_t type, const double* inv, const double* e, D3 point
 #pragma unroll
     for (int k = 0; k < 4; ++k) occ |= (h.t[k] > 0.0) & (h.t[k] < distance);  // (absent = +inf)
     return occ;
+}
+// group.rs:107 + bounding_box.rs:81-84 in f64: the ray sees a primitive only if it enters the box of every Group around
+// it (tmin < tmax, strict).  For the rays whose FP32 answer was a near thing (rt_math.h gates_pass_near): XGate is the
+// caller's own f64 box of a Group (rt_scene_desc.node_box64), parallel to DGate, whose `parent` links are followed.
+struct XGate {
+    double mn[3], mx[3];
+};
+RT_HD bool xgates_pass(const DGate* gates, const XGate* xgates, uint32_t g, D3 o, D3 d) {
+    while (g != kNoGate) {
+        const XGate& G = xgates[g];
+        double x0, x1, y0, y1, z0, z1;
+        xcheck_axis(o.x, d.x, G.mn[0], G.mx[0], x0, x1);
+        xcheck_axis(o.y, d.y, G.mn[1], G.mx[1], y0, y1);
+        xcheck_axis(o.z, d.z, G.mn[2], G.mx[2], z0, z1);
+        if (!(xmax_by3(x0, y0, z0) < xmin_by3(x1, y1, z1))) return false;
+        g = gates[g].parent;
+    }
+    return true;
+}
+// ... for a shadow ray: the ray World::is_shadowed forms (world.rs:82-84), as in xoccludes
+RT_HD bool xgates_pass_shadow(const DGate* gates, const XGate* xgates, uint32_t g, D3 point, D3 light_position) {
+    D3 dir = d3(0.0, 0.0, 0.0);
+    if (!xnormalize(light_position - point, dir)) return false;
+    return xgates_pass(gates, xgates, g, point, dir);
 }
 // The jitter draws of rt_math.h counter_jitter as the reference forms them: byte as f64 / 255.0
 RT_HD void xcounter_jitter(uint32_t pixel_key, uint32_t node, uint32_t light, uint32_t cell, double& ju, double& jv) {

@@ -88,6 +88,13 @@
 #ifndef RT_FIX_PARTS
 #define RT_FIX_PARTS 3  // experiments: bit 0 = the over_mid rows are written, bit 1 = the private record list and its flush exist
 #endif
+#ifndef RT_GATE_NEAR
+// Group boxes clipped near an edge go to f64 (rt_math.h gates_pass_near): 1 = for the winner of the nearest-hit search,
+// 2 = in the shadow walks, 4 = in the second count.  1 and 2 only in the EXOTIC kernels: in the others their mere code cost
+// C4 3-5 %, cover_image 0-5 % and cover_image_area 11-13 % (profiles/r03_group_boxes.txt) for a case their scenes cannot
+// have without a cube's corner on its Group's box — a sphere does not reach the edges of a box around it.
+#define RT_GATE_NEAR 7
+#endif
 #ifndef RT_NO_NEAR
 #define RT_NO_NEAR 0  // experiments: 1 = the plain any-hit tests (what noting the near things costs)
 #endif
@@ -132,6 +139,7 @@ struct KScene {
     const double* xior;
     const XPattern* xpats;
     const XLight* xlights;  // per light (always there: the caller's f64 geometry, or the f32 values widened)
+    const XGate* xgates;    // per Group, parallel to `gates` (always there: the caller's f64 boxes, or the f32 values widened)
     uint32_t n_items, n_lights;
     uint32_t has_gates, has_bvh;
     uint32_t any_spawn;  // some material is reflective or transparent (no path has a second node otherwise)
@@ -421,7 +429,10 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
                 hit = occludes_prim<EXOTIC>(p, sc.extras, ray.o, ray.d, dist);
 #endif
             }
-            if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);  // group.rs:107
+            if ((TREE && sc.has_gates) && hit) {  // group.rs:107
+                if constexpr (NEAR && EXOTIC && (RT_GATE_NEAR & 2) != 0) hit = gates_pass_near(sc.gates, sc.gate[prim], ray.o, ray.d, near);
+                else hit = gates_pass(sc.gates, sc.gate[prim], ray.o, ray.d);
+            }
             occ = hit;
             return !occ;
         };
@@ -453,9 +464,10 @@ __device__ __forceinline__ bool fix_occluded(const KScene& sc, uint32_t self_pri
         }
         ShadowTest st{true, false};
         if (i != self_prim) st = occludes_prim_soft<EXOTIC>(p, sc.extras, o, d, w);
-        bool hit = st.maybe;
-        if (hit && sc.has_gates) hit = gates_pass(sc.gates, sc.gate[i], o, d);  // group.rs:107
+        bool hit = st.maybe, gate_near = false;
+        if (hit && sc.has_gates) hit = (RT_GATE_NEAR & 4) ? gates_pass_near(sc.gates, sc.gate[i], o, d, gate_near) : gates_pass(sc.gates, sc.gate[i], o, d);  // group.rs:107
         if (hit && !st.sure) hit = xoccludes<EXOTIC>(p.type, sc.xprims[i].inv, sc.xextras[p.extra].f, o64, lp64);
+        if ((RT_GATE_NEAR & 4) && hit && gate_near) hit = xgates_pass_shadow(sc.gates, sc.xgates, sc.gate[i], o64, lp64);
         occ = hit;
         ++i;
     }
@@ -821,8 +833,23 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         };
         do_trace(active);
         if (EXACT) {
-            const bool retry = do_select(active, true);
-            if (wave_any(retry)) {  // rare: a grazing FP32 hit that f64 does not confirm
+            // A winner inside a Group whose box the ray clips within FP32 reach of an edge (rt_math.h gates_pass_near: the
+            // FP32 boxes let in a superset): the reference's own test with the caller's own box (group.rs:107 in f64,
+            // rt_exact.h xgates_pass) says whether the ray sees it; if not, the search runs again without it.
+            bool gate_out = false;
+            if constexpr (TREE && EXOTIC && (RT_GATE_NEAR & 1) != 0) {
+                bool ask = false;  // (asked of the winner after the search: carried through it, the flag costs the walks registers)
+                if (sc.has_gates && active && hit_prim != kNoPrim) gates_pass_near(sc.gates, sc.gate[hit_prim], cur.o, cur.d, ask);
+                if (sc.has_gates && wave_any(ask)) {  // rare
+                    if (ask) {
+                        const Ray64 r = cur64();
+                        gate_out = !xgates_pass(sc.gates, args_here().sc.xgates, sc.gate[hit_prim], r.o, r.d);
+                    }
+                    if (gate_out) excl0 = hit_prim, hit_prim = kNoPrim, hit_t = INFINITY, alt_prim = kNoPrim, alt_t = INFINITY, hit_unsure = false;
+                }
+            }
+            const bool retry = do_select(active && !gate_out, true) || gate_out;
+            if (wave_any(retry)) {  // rare: a grazing FP32 hit that f64 does not confirm, a winner its Group hides
                 do_trace(retry);
                 do_select(retry, false);
             }
@@ -1296,7 +1323,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                                     } else {
                                         hit = occludes_prim<EXOTIC>(rec, sc.extras, sr.o, sr.d, dist);
                                     }
-                                    if ((TREE && sc.has_gates) && hit) hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);  // group.rs:107
+                                    if ((TREE && sc.has_gates) && hit) {  // group.rs:107
+                                        if constexpr (EXACT && EXOTIC && !RT_NO_NEAR && (RT_GATE_NEAR & 2) != 0) hit = gates_pass_near(sc.gates, sc.gate[i], sr.o, sr.d, band);
+                                        else hit = gates_pass(sc.gates, sc.gate[i], sr.o, sr.d);
+                                    }
                                 }
                                 if (hit) occ_bits |= 1ull << cell;
                                 if (STATS && first && mine && ray) c_shadow++, c_cast++;

@@ -406,34 +406,54 @@ RT_HD void isect_cube(V3 o, V3 d, bool self, V3 q, V3 dq, Emit&& emit, Soft&& so
 }
 
 // cylinder.rs:126-225
-RT_HD bool cyl_check_cap(float ox, float oz, float dx, float dz, float t) {
+// Near things of a cylinder (as for the sphere above: kUnsure on a hit, `soft` for a miss): a ray that grazes the wall,
+// a wall crossing at the height of a rim (cylinder.rs:171-181, strict ymin < y < ymax), a cap crossing at the rim's
+// radius (cylinder.rs:200-215).
+RT_HD float cyl_cap_rr(float ox, float oz, float dx, float dz, float t) {
     float x = fmaf(t, dx, ox), z = fmaf(t, dz, oz);
-    float rr = fmaf(x, x, z * z);
-    return rr <= 1.0f + kEps;  // le(x^2 + z^2, 1)
+    return fmaf(x, x, z * z);  // le(x^2 + z^2, 1) follows
 }
-template <class Emit>
-RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float ymax, bool closed, Emit&& emit) {
+template <class Emit, class Soft>
+RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float ymax, bool closed, Emit&& emit, Soft&& soft) {
     V3 os = self ? q + dq : o;
     float a = fmaf(d.x, d.x, d.z * d.z);
     if (!approx(a, 0.0f)) {
         float t0, t1;
+        int unsure = 0;
         if (self && q.y != ymin && q.y != ymax && fabsf(fmaf(q.x, q.x, q.z * q.z) - 1.0f) < 1e-5f) {
             // origin on the wall (prepare_hit normalised q there; a point it snapped onto a CAP has q.y == ymin / ymax
             // and may lie anywhere inside the rim, 1e-4 from it included): q_x^2 + q_z^2 == 1, c has no cancellation
             float h = fmaf(os.x, d.x, os.z * d.z);  // b/2
             float c = fmaf(2.0f, fmaf(q.x, dq.x, q.z * dq.z), fmaf(dq.x, dq.x, dq.z * dq.z));
-            if (!on_surface_roots(a, h, c, t0, t1)) return;  // cylinder.rs:140-142 returns WITHOUT testing the caps
+            const float disc = fmaf(h, h, -(a * c));
+            const bool graze = disc * disc < 64e-12f * a * (h * h);  // (isect_sphere: the ray leaves its own wall tangentially)
+            if (!on_surface_roots(a, h, c, t0, t1)) {  // cylinder.rs:140-142 returns WITHOUT testing the caps
+                if (graze) soft(-h * rcp_f(a));
+                return;
+            }
+            unsure = graze ? kUnsure : 0;
         } else {
             // the sphere_foot construction in the xz plane
             float tc, half;
             V3 l;
-            if (!sphere_foot(v3(os.x, 0.0f, os.z), v3(d.x, 0.0f, d.z), a, tc, l, half)) return;
+            const bool ok = sphere_foot(v3(os.x, 0.0f, os.z), v3(d.x, 0.0f, d.z), a, tc, l, half);
+            const float m = 1.0f - dot(l, l);
+            if (!ok) {
+                if (m > -kGraze) soft(tc);
+                return;
+            }
+            unsure = m < kGraze ? kUnsure : 0;
             t0 = tc - half, t1 = tc + half;
         }
-        float y0 = fmaf(t0, d.y, os.y);
-        if (ymin < y0 && y0 < ymax) emit(0, t0, 0.0f, 0.0f);
-        float y1 = fmaf(t1, d.y, os.y);
-        if (ymin < y1 && y1 < ymax) emit(1, t1, 0.0f, 0.0f);
+        auto wall = [&](int slot, float t) {
+            const float y = fmaf(t, d.y, os.y);
+            const float room = kGraze * fmaxf(1.0f, fabsf(y));
+            const bool rim = fabsf(y - ymin) < room || fabsf(y - ymax) < room;  // (an open end at +-inf is never near)
+            if (ymin < y && y < ymax) emit(slot | unsure | (rim ? kUnsure : 0), t, 0.0f, 0.0f);
+            else if (rim) soft(t);
+        };
+        wall(0, t0);
+        wall(1, t1);
     }
     if (!closed || approx(d.y, 0.0f)) return;  // cylinder.rs:192
     float nlo, nhi;
@@ -445,10 +465,14 @@ RT_HD void isect_cylinder(V3 o, V3 d, bool self, V3 q, V3 dq, float ymin, float 
         nhi = ymax - o.y;
     }
     float inv_dy = rcp_f(d.y);
-    float t = nlo * inv_dy;
-    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) emit(2, t, 0.0f, 0.0f);
-    t = nhi * inv_dy;
-    if (cyl_check_cap(os.x, os.z, d.x, d.z, t)) emit(3, t, 0.0f, 0.0f);
+    auto cap = [&](int slot, float t) {
+        const float rr = cyl_cap_rr(os.x, os.z, d.x, d.z, t);
+        const bool rim = fabsf(rr - 1.0f) < kGraze;
+        if (rr <= 1.0f + kEps) emit(slot | (rim ? kUnsure : 0), t, 0.0f, 0.0f);
+        else if (rim) soft(t);
+    };
+    cap(2, nlo * inv_dy);
+    cap(3, nhi * inv_dy);
 }
 
 // triangle.rs:104-133 (Moller-Trumbore); e = {v0, e0, e1}
@@ -501,7 +525,7 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
             if (!EXOTIC) break;
             V3 o = xform_point(p.inv, ray.o), d = xform_vector(p.inv, ray.d);
             const float* e = extras[p.extra].f;
-            isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, emit);
+            isect_cylinder(o, d, self, ray.q, ray.dq, e[0], e[1], e[2] != 0.0f, emit, soft);
             break;
         }
         default: {  // PRIM_TRIANGLE, PRIM_SMOOTH
@@ -524,6 +548,7 @@ RT_HD void intersect_prim(const DPrim& p, const DExtra* extras, const Ray& ray, 
 // positive hit is closer than the light iff ANY positive hit is).  For a ray that does NOT start on
 // the primitive the three common shapes answer without a branch; the others go through the emitter.
 RT_HD bool in_range(float t, float dist) { return (t > 0.0f) & (t < dist); }
+RT_HD bool in_win(float t, float lo, float hi) { return (t > lo) & (t < hi); }
 template <bool EXOTIC = true>
 RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, float dist) {
     switch (p.type) {
@@ -580,9 +605,22 @@ RT_HD bool occludes_prim_near(const DPrim& p, const DExtra* extras, V3 ro, V3 rd
             near |= fabsf(tmax - tmin) <= kGraze * fmaxf(1.0f, fabsf(tmax));
             return !(tmin > tmax) & (in_range(tmin, dist) | in_range(tmax, dist));
         }
-        // Planes have no near things of their own.  Cylinders report none; a ray past a triangle's edge almost always
-        // belongs to a mesh whose next triangle takes it (every shadow ray of obj_mesh near ANY edge would leave a record:
-        // 0.48 -> 1.47 ms): the plain test.
+        case PRIM_CYLINDER: {  // a grazed wall, a crossing at a rim: isect_cylinder's near things, if they lie before the light
+            if (!EXOTIC) return false;
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            const float* e = extras[p.extra].f;
+            bool occ = false;
+            const float w0 = amb_window(0.0f), w1 = amb_window(dist);
+            isect_cylinder(
+                o, d, false, v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 0.0f), e[0], e[1], e[2] != 0.0f,
+                [&](int slot, float t, float, float) { occ |= in_range(t, dist), near |= (slot & kUnsure) != 0 && in_win(t, -w0, dist + w1); },
+                [&](float t) { near |= in_win(t, -w0, dist + w1); });
+            return occ;
+        }
+        // Planes have no near things of their own.  Triangles report none to the shadow rays: the second count of a
+        // record costs a walk of one lane, and every shadow ray that passes ANY edge of a mesh within kGraze would leave one
+        // (obj_mesh: 0.44 -> 1.45 ms for no pixel of its census; shapes_zoo keeps ONE pixel above 1e-4 for it,
+        // profiles/r03_parity_census.txt): the plain test.
         default: return occludes_prim<EXOTIC>(p, extras, ro, rd, dist);
     }
 }
@@ -618,7 +656,6 @@ RT_HD ShadowWin shadow_windows(float dist) {
 struct ShadowTest {
     bool maybe, sure;
 };
-RT_HD bool in_win(float t, float lo, float hi) { return (t > lo) & (t < hi); }
 // The primitive the shadow ray STARTS on: its self form (rt_math.h "self") knows the crossing it stands on exactly, so
 // the plain range (0, dist) applies; what it cannot settle is a ray that grazes its own sphere (kUnsure roots, or a
 // near miss reported to `soft`).
@@ -705,6 +742,25 @@ RT_HD bool gates_pass(const DGate* gates, uint32_t g, V3 o, V3 d) {
         if (!(tmin < tmax)) return false;
         g = G.parent;
     }
+    return true;
+}
+
+// The same for the kernels with the f64 chain, which also want to know whether some box on the way was a near thing.
+// The boxes here are the caller's, rounded to FP32 and padded outwards (rt_pack.h widen), so what passes here is a
+// superset of what passes in the reference; a ray whose way through a box is shorter than kGraze (the rule of the cube's
+// edges, isect_cube) clips it so close to an edge that only f64 with the caller's own box (rt_exact.h xgates_pass) can say
+// whether the reference lets it in.
+RT_HD bool gates_pass_near(const DGate* gates, uint32_t g, V3 o, V3 d, bool& near) {
+    bool n = false;  // (a ray that FP32 keeps out of some box stays out in f64 too: nothing near about it)
+    while (g != kNoGate) {
+        const DGate G = gates[g];
+        float tmin, tmax;
+        isect_box(v3(G.mn[0], G.mn[1], G.mn[2]) - o, v3(G.mx[0], G.mx[1], G.mx[2]) - o, d, tmin, tmax);
+        if (!(tmin < tmax)) return false;
+        n |= tmax - tmin <= kGraze * fmaxf(1.0f, fabsf(tmax));
+        g = G.parent;
+    }
+    near |= n;
     return true;
 }
 

@@ -68,6 +68,7 @@ struct PackedScene {
     uint32_t top_k = 0;               // records in use per top region; 0 = no staged top
     uint32_t n_top = 0;           // records in front of the hierarchy's root (unbounded primitives)
     std::vector<DGate> gates;     // the caller's Groups
+    std::vector<XGate> xgates;    // ... and their boxes in the caller's own f64 (node_box64), or the f32 values widened
     PodVec<DExtra> extras;
     std::vector<DMaterial> mats;
     std::vector<DPattern> pats;
@@ -803,6 +804,12 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
                     open_gate.push_back(static_cast<uint32_t>(out.gates.size()));
                 }
                 out.gates.push_back(g);
+                XGate xg{};
+                for (int k = 0; k < 3; ++k) {
+                    xg.mn[k] = d->node_box64 ? d->node_box64[6 * n + k] : static_cast<double>(d->node_min[3 * n + k]);
+                    xg.mx[k] = d->node_box64 ? d->node_box64[6 * n + 3 + k] : static_cast<double>(d->node_max[3 * n + k]);
+                }
+                out.xgates.push_back(xg);
             } else {
                 if (ref >= d->n_prims) return bad("item primitive index out of range");
                 if (next != i + 1) return bad("a primitive item must link to the next item");
@@ -815,7 +822,7 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
             }
         }
     }
-    if (out.gates.empty()) out.gates.push_back(DGate{});
+    if (out.gates.empty()) out.gates.push_back(DGate{}), out.xgates.push_back(XGate{});
 
     RT_PACK_MARK(3);
     // Lay the stream out: unbounded primitives (and everything, in a flat scene) in front, in world.objects order, then the

@@ -58,6 +58,15 @@ void traverse(const Sim& s, const Ray& ray, float t_lo, THi&& t_hi, Visit&& visi
 bool gated_in(const Sim& s, uint32_t prim, const Ray& ray) {
     return !s.ps.has_gates || gates_pass(s.ps.gates.data(), s.ps.gate[prim], ray.o, ray.d);
 }
+// ... and whether some Group's box on the way was a near thing (rt_math.h gates_pass_near)
+bool gated_in_near(const Sim& s, uint32_t prim, V3 o, V3 d, bool& near) {
+    return !s.ps.has_gates || gates_pass_near(s.ps.gates.data(), s.ps.gate[prim], o, d, near);
+}
+// (the render kernels ask only in their EXOTIC instantiations, rt_kernel.h RT_GATE_NEAR; the second count always)
+bool gated_in_near_first_pass(const Sim& s, uint32_t prim, V3 o, V3 d, bool& near) {
+    if (!s.ps.exotic) return !s.ps.has_gates || gates_pass(s.ps.gates.data(), s.ps.gate[prim], o, d);
+    return gated_in_near(s, prim, o, d, near);
+}
 
 Closest closest_hit(const Sim& s, const Ray& ray, uint32_t excl0 = kNoPrim, uint32_t excl1 = kNoPrim) {
     Closest c{kNoPrim, INFINITY, 0.0f, 0.0f};
@@ -112,7 +121,7 @@ bool occluded_near(const Sim& s, const Ray& ray, float dist, bool& near) {
         bool hit;
         if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
         else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
-        occ = hit && gated_in(s, prim, ray);
+        occ = hit && gated_in_near_first_pass(s, prim, ray.o, ray.d, near);
         return !occ;
     });
     return occ;
@@ -127,11 +136,13 @@ bool occluded_fix(const Sim& s, uint32_t self_prim, V3 o, V3 d, float dist, D3 o
     traverse(s, ray, w.lo_m, [&] { return w.hi_m; }, [&](uint32_t prim, const DPrim& p) {
         ShadowTest st{true, false};
         if (prim != self_prim) st = occludes_prim_soft(p, s.ps.extras.data(), o, d, w);
-        bool hit = st.maybe && gated_in(s, prim, ray);
+        bool gate_near = false;
+        bool hit = st.maybe && gated_in_near(s, prim, o, d, gate_near);
         if (hit && !st.sure) {
             g_sh_f64 += 1;
             hit = xoccludes(p.type, s.ps.xprims[prim].inv, s.ps.xextras[p.extra].f, over64, light64);
         }
+        if (hit && gate_near) hit = xgates_pass_shadow(s.ps.gates.data(), s.ps.xgates.data(), s.ps.gate[prim], over64, light64);
         occ = hit;
         return !occ;
     });
@@ -363,6 +374,18 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             // (the same two steps as rt_kernel.h: selection in f64 among what FP32 could not order and for every
             // node that spawns children; then, for a hit that stands, the pattern / edge decisions)
             for (int attempt = 0; attempt < 2; ++attempt) {
+                // a winner inside a Group whose box the ray clips within FP32 reach of an edge (rt_kernel.h "gate_out"): the
+                // reference's own test in f64; if the ray does not see it, the search runs again without it
+                if (attempt == 0 && s.ps.has_gates && s.ps.exotic && c.prim != kNoPrim) {
+                    bool gate_near = false;
+                    gated_in_near(s, c.prim, cur.ray.o, cur.ray.d, gate_near);
+                    if (gate_near && !xgates_pass(s.ps.gates.data(), s.ps.xgates.data(), s.ps.gate[c.prim], cur.o64, cur.d64)) {
+                        g_x_retry += 1;
+                        c = closest_hit(s, cur.ray, c.prim, kNoPrim);
+                        hit_prim = c.prim, hit_t = c.t, hit_u = c.u, hit_v = c.v;
+                        attempt = 1;
+                    }
+                }
                 bool amb = c.unsure || c.alt != kNoPrim;
                 bool why_children = false;
                 const bool why_pattern = false, why_edge = false;

@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header():
     # field order/size as in include/rt_amd.h (natural C alignment on x86-64)
     assert C.sizeof(RtCameraDesc) == 4 * 5 + 4 * 12 + 4 + 8 * 15  # f32 fields, has_f64, 15 doubles
     assert C.sizeof(RtOptions) == 7 * 4
-    assert C.sizeof(RtSceneDesc) == 8 + 5 * 8 + 26 * 8  # (abi_version, n_prims) + 5 padded counts + 26 pointers
+    assert C.sizeof(RtSceneDesc) == 8 + 5 * 8 + 27 * 8  # (abi_version, n_prims) + 5 padded counts + 27 pointers
 
 
 def _arr(ptr, ctype, shape):
