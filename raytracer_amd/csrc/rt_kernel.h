@@ -86,7 +86,7 @@
 #define RT_NO_EMIT 0  // experiments: 1 = no FixRecords (what writing them costs the shading loops), 2 = nor their LDS rows and private list
 #endif
 #ifndef RT_FIX_PARTS
-#define RT_FIX_PARTS 3  // experiments: bit 0 = the over_mid rows are written, bit 1 = the private record list and its flush exist
+#define RT_FIX_PARTS 3  // experiments: bit 0 = the f64 over point of a refined node is kept for the records, bit 1 = the private record list and its flush exist
 #endif
 #ifndef RT_GATE_NEAR
 // Group boxes clipped near an edge go to f64 (rt_math.h gates_pass_near): 1 = for the winner of the nearest-hit search,
@@ -113,10 +113,11 @@ struct FixRecord {
     float k[3];          // colour per unoccluded cell: weight x (diffuse and specular sums) / samples^2
     float lit;           // the count the shading loop used
     uint32_t hit_prim;
-    float over[3];       // the node's over point: FP32 value, + the next 24 bits of the f64 value of a refined node
-    float over_mid[3];
+    float spare[6];
     uint32_t scratch[5]; // (private bookkeeping of the list, rt_kernel.h `pend`)
-    double ray[6];       // a node that was not refined (and is not the camera ray's): its f64 ray
+    double ray[6];       // a node that was not refined (and is not the camera ray's): its f64 ray (origin, direction);
+                         // a refined node: ray[0..2] = its f64 over point, every bit of it — a point whose shadow rays
+                         // hang on the reference's own rounding noise (XHit::qedge) is decided 1e-16 from the surface
 };
 static_assert(sizeof(FixRecord) == 128, "FixRecord layout");
 
@@ -696,9 +697,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     constexpr uint32_t kPend = RT_PEND;
     FixRecord pend[(EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) ? kPend : 1];
     if (EXACT && RT_NO_EMIT < 2 && (RT_FIX_PARTS & 2)) pend[0].scratch[0] = 0u;
-    // ... and, in three more words of pend[0] no record uses (scratch[1..3]), what the f64 over point of the
-    // current node holds beyond its FP32 value if the node was refined (private as well: three LDS rows for it cost
-    // cover_image_area a wave per CU, 2.0 -> 2.15 ms)
+    // ... and, in six more words no record uses (pend[0].scratch[1..4], pend[1].scratch[0..1]), the f64 over point of the
+    // current node if the node was refined (private as well: three LDS rows for its middle bits cost cover_image_area a
+    // wave per CU, 2.0 -> 2.15 ms)
     // The f64 camera (30 dwords of kernel arguments) and the pointers of the f64 tables are read WHERE they are used —
     // refined nodes, second counts — through an address the compiler cannot move out of the path loop (n_rounds never reaches
     // 2^31, which it cannot know): read as plain `P.cam64`, `sc.xprims` their loads were hoisted to the kernel's entry, and
@@ -948,10 +949,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const XHit xh = xprepare<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, r.o, r.d, t64, u64, v64);
             over = to_v3(xh.over), nrm = to_v3(xh.normal), hit_inside = xh.inside;
             qedge = xh.qedge;
-            if constexpr (kFix && (RT_FIX_PARTS & 1)) {  // (what the f64 over point holds beyond its FP32 value: 48 of its 53 bits travel to the fix kernel)
-                const D3 rest = xh.over - to_d3(over);
-                pend[0].scratch[1] = __float_as_uint(static_cast<float>(rest.x)), pend[0].scratch[2] = __float_as_uint(static_cast<float>(rest.y));
-                pend[0].scratch[3] = __float_as_uint(static_cast<float>(rest.z));
+            if constexpr (kFix && (RT_FIX_PARTS & 1)) {  // (the f64 over point travels to the second count whole)
+                pend[0].scratch[1] = static_cast<uint32_t>(__double2loint(xh.over.x)), pend[0].scratch[2] = static_cast<uint32_t>(__double2hiint(xh.over.x));
+                pend[0].scratch[3] = static_cast<uint32_t>(__double2loint(xh.over.y)), pend[0].scratch[4] = static_cast<uint32_t>(__double2hiint(xh.over.y));
+                pend[1].scratch[0] = static_cast<uint32_t>(__double2loint(xh.over.z)), pend[1].scratch[1] = static_cast<uint32_t>(__double2hiint(xh.over.z));
             }
             // (the rays that leave this point start at the f64 point: their "self" form must stand on the same point.  The
             // FP32 hit point of a grazing ray is 1e-6 / |n . d| along the surface from it — 1e-4 in random_stress:162 —
@@ -1040,11 +1041,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         const V3 k = v3(park[0 * kBlockThreads], park[1 * kBlockThreads], park[2 * kBlockThreads]) * shade * (inv_samples * inv_samples);
                         r.k[0] = k.x, r.k[1] = k.y, r.k[2] = k.z, r.lit = lit_count;
                         r.hit_prim = h_prim();
-                        const V3 o = h_over();
-                        r.over[0] = o.x, r.over[1] = o.y, r.over[2] = o.z;
-                        r.over_mid[0] = refined ? __uint_as_float(pend[0].scratch[1]) : 0.0f, r.over_mid[1] = refined ? __uint_as_float(pend[0].scratch[2]) : 0.0f;
-                        r.over_mid[2] = refined ? __uint_as_float(pend[0].scratch[3]) : 0.0f;
-                        if (!refined && node != 0u) {  // (its ray is still where it was: only a refined node writes its children's rays early;
+                        if (refined) {
+                            r.ray[0] = __hiloint2double(static_cast<int>(pend[0].scratch[2]), static_cast<int>(pend[0].scratch[1]));
+                            r.ray[1] = __hiloint2double(static_cast<int>(pend[0].scratch[4]), static_cast<int>(pend[0].scratch[3]));
+                            r.ray[2] = __hiloint2double(static_cast<int>(pend[1].scratch[1]), static_cast<int>(pend[1].scratch[0]));
+                        } else if (node != 0u) {  // (its ray is still where it was: only a refined node writes its children's rays early;
                             const Ray64 rr = r64_load(cur_slot);  //  the camera ray is worked out from the pixel when the record leaves)
                             r.ray[0] = rr.o.x, r.ray[1] = rr.o.y, r.ray[2] = rr.o.z, r.ray[3] = rr.d.x, r.ray[4] = rr.d.y, r.ray[5] = rr.d.z;
                         }
@@ -1610,8 +1611,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             };
             const uint32_t pl = wd(0), li = wd(1) & 0x7FFFFFFFu, at_node = wd(2), key = wd(3), self_prim = wd(8);
             const bool was_refined = (wd(1) >> 31) != 0u;
-            D3 over64 = d3(static_cast<double>(fl(9)) + static_cast<double>(fl(12)), static_cast<double>(fl(10)) + static_cast<double>(fl(13)),
-                           static_cast<double>(fl(11)) + static_cast<double>(fl(14)));
+            D3 over64 = d3(db(20), db(22), db(24));  // (a refined node's)
             bool ok = li < sc.n_lights && self_prim < sc.n_items;
 #ifdef RT_FIX_STUB  // experiment: the second count without its arithmetic (what the block's mere presence costs)
             ok = false;

@@ -121,7 +121,9 @@ bool occluded_near(const Sim& s, const Ray& ray, float dist, bool& near) {
         bool hit;
         if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
         else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
-        occ = hit && gated_in_near_first_pass(s, prim, ray.o, ray.d, near);
+        { bool n0 = near; occ = hit && gated_in_near_first_pass(s, prim, ray.o, ray.d, near);
+          static const bool dbg = getenv("RT_DBG") != nullptr;
+          if (dbg) fprintf(stderr, "DBG sh prim %u type %u self %d hit %d occ %d near %d->%d dist %.7g o (%.8g %.8g %.8g) d (%.8g %.8g %.8g)\n", prim, p.type, (int)(prim == ray.self), (int)hit, (int)occ, (int)n0, (int)near, dist, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z); }
         return !occ;
     });
     return occ;
@@ -479,16 +481,14 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     phong_cell(phong_point(over, h.n, h.eye, m.shininess), centre, ldn, spec);
                     sum_d += ldn, sum_s += spec;
                 }
+                { static const bool dbg = getenv("RT_DBG") != nullptr; if (dbg) fprintf(stderr, "DBG node %u light %u lit %u near_any %d refined %d qedge %d hit_prim %u\n", cur.node, li, lit, (int)near_any, (int)refined, (int)(refined && xh.qedge), hit_prim); }
                 if (s.exact && (near_any || (refined && xh.qedge))) {
                     // rt_kernel.h "unsure shadow rays": a FixRecord, and the fix kernel counts this light's cells again
                     g_sh_redo += 1, g_sh_why_near += near_any, g_sh_why_qedge += refined && xh.qedge;
                     D3 over64;
                     bool ok = true;
-                    if (refined) {  // (48 of the 53 bits travel: FixRecord::over + over_mid)
-                        const D3 rest = xh.over - to_d3(over);
-                        const V3 mid = to_v3(rest);
-                        over64 = d3(static_cast<double>(over.x) + static_cast<double>(mid.x), static_cast<double>(over.y) + static_cast<double>(mid.y),
-                                    static_cast<double>(over.z) + static_cast<double>(mid.z));
+                    if (refined) {  // (the f64 over point travels whole: FixRecord::ray[0..2])
+                        over64 = xh.over;
                     } else {  // the node's f64 hit, worked out again from its f64 ray
                         const XHits ha = xintersect(p.type, s.ps.xprims[hit_prim].inv, s.ps.xextras[p.extra].f, cur.o64, cur.d64);
                         double ft = 0.0, fu = 0.0, fv = 0.0;
