@@ -307,6 +307,7 @@ int render_host(rt_scene* scene, const rt_camera_desc* camera, const rt_options*
 #ifdef RT_PHASE_CLOCK
             std::fprintf(stderr, "phase ticks (summed over waves): trace %llu prepare+containers %llu f64 %llu shade %llu children %llu | loop iterations %llu\n",
                          c[10], c[11], c[12], c[13], c[14], c[15]);
+            std::fprintf(stderr, "second count: ticks (summed over waves) %llu, records %llu, walk steps %llu, the longest wave's ticks %llu\n", c[16], c[17], c[18], c[19]);
 #endif
         }
     }

@@ -164,7 +164,7 @@ struct KParams {
 
 constexpr int kStackCap = 8;  // RT_MAX_DEPTH
 #ifdef RT_PHASE_CLOCK  // experiment: + iterations of the path loop and s_memtime ticks per phase, summed over waves
-constexpr int kCounters = 16;
+constexpr int kCounters = 20;  // + second count: ticks, records, walk steps, the longest wave's ticks
 #define RT_TICK(k)                                             \
     if (STATS) {                                               \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -453,11 +453,12 @@ __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float
 // xoccludes: world.rs:73-92) from the f64 over point to the f64 light position where they are not, and always for the
 // primitive the point stands on.
 template <bool EXOTIC>
-__device__ __forceinline__ bool fix_occluded(const KScene& sc, uint32_t self_prim, V3 o, V3 d, float dist, D3 o64, D3 lp64) {
+__device__ __forceinline__ bool fix_occluded(const KScene& sc, uint32_t self_prim, V3 o, V3 d, float dist, D3 o64, D3 lp64, unsigned long long* steps = nullptr) {
     const ShadowWin w = shadow_windows(dist);
     const V3 inv_d = inv_dir(d);
     bool occ = false;
     for (uint32_t i = 0; i < sc.n_items && !occ;) {
+        if (steps) ++*steps;
         const DPrim p = sc.recs[i];
         if (p.type == REC_NODE) {
             i = bvh_node_hit(p, o, inv_d, w.lo_m, w.hi_m) ? i + 1u : p.material;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                        c_cells = 0, c_pattern = 0, c_container = 0, c_cast = 0, c_refined = 0;
 
 #ifdef RT_PHASE_CLOCK
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     while (wave_any(active)) {
@@ -1590,12 +1591,18 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         // lane, each lane's from the last to the first (one order, whatever happens around the wave).  The record goes
         // through an LDS row (the park rows are free now) to all 64 lanes, which count the light's cells, a cell a lane.
         uint32_t n_mine = P.no_fix ? 0u : pend[0].scratch[0];
+#ifdef RT_PHASE_CLOCK
+        const unsigned long long t_fix = __builtin_amdgcn_s_memtime();
+#endif
         float* const ex = s_park + (threadIdx.x & ~63u) + 6 * kBlockThreads;  // 32 words of row 6 (rows 3..5 may hold the pixel sums)
 #pragma unroll 1
         for (;;) {
             const unsigned long long mm = wave_ballot(n_mine != 0u);
             if (mm == 0ull) break;
             const int src = __ffsll(static_cast<long long>(mm)) - 1;
+#ifdef RT_PHASE_CLOCK
+            ph[7]++;
+#endif
             if (static_cast<int>(lane) == src) {
                 --n_mine;
                 const FixRecord r = pend[n_mine < kPend ? n_mine : 0u];
@@ -1660,7 +1667,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                         unocc = true;
                         if (dist2 > 0.0f) {  // (a null vector is lit, world.rs:77-81: xoccludes decides that in f64)
                             const float inv_dist = rsq_f(dist2);
+#ifdef RT_PHASE_CLOCK
+                            unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64, &ph[8]);
+#else
                             unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
+#endif
                         }
                     }
                     lit += static_cast<uint32_t>(__popcll(wave_ballot(unocc)));
@@ -1680,6 +1691,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
+#ifdef RT_PHASE_CLOCK
+        if (STATS) ph[6] = __builtin_amdgcn_s_memtime() - t_fix;
+#endif
     }
     {
         // the pixel's coordinates are worked out again rather than kept in registers (or spilled to
@@ -1703,7 +1717,9 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     if (STATS) {
         unsigned long long v[kCounters] = {c_primary, c_reflect, c_refract, c_shadow, c_shaded, c_cells, c_pattern, c_container, c_cast, c_refined};
 #ifdef RT_PHASE_CLOCK
-        for (int k = 0; k < 6; ++k) v[kCountersBase + k] = lane == 0 ? ph[k] : 0ull;
+        for (int k = 0; k < 9; ++k) v[kCountersBase + k] = (lane == 0 || k == 8) ? ph[k] : 0ull;
+        v[kCountersBase + 9] = 0ull;
+        if (lane == 0) atomicMax(P.counters + kCountersBase + 9, ph[6]);
 #endif
         unsigned long long cast_rays = 0;  // primary + reflection + refraction + shadow rays really traced
         for (int k = 0; k < kCounters; ++k) {

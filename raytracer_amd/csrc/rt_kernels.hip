@@ -29,6 +29,8 @@ constexpr KernelFn pick() {
     return render_kernel<S, false, false, true, kX, false, kP>;
 #elif defined(RT_EXP_ONLY_TREE_AREA)  // (cover_image_area's kernels only)
     return render_kernel<S, false, true, true, kX, false, true>;
+#elif defined(RT_EXP_ONLY_TREE_EXOTIC)  // (obj_mesh's and the triangle soups' kernels only)
+    return render_kernel<S, true, true, false, kX, kL, true>;
 #else
     if constexpr (kL && !T) return nullptr;  // lane mode needs a hierarchy
     else return render_kernel<S, E, T, A, kX, kL, kP>;

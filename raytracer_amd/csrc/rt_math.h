@@ -585,6 +585,9 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
 // `near` = the ray grazes this sphere or the edge of this cube (the two near things a point in the open meets; a point
 // within 1e-4 of another surface is known from the nearest-hit search: its second candidate).  One compare a sphere,
 // four instructions a cube.
+#ifndef RT_TRI_NEAR
+#define RT_TRI_NEAR 0  // experiment: triangle edges are near things for the shadow rays too (profiles/r03_group_boxes.txt)
+#endif
 constexpr float kNearSphere = 2e-5f;
 template <bool EXOTIC = true>
 RT_HD bool occludes_prim_near(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, float dist, bool& near) {
@@ -621,7 +624,22 @@ RT_HD bool occludes_prim_near(const DPrim& p, const DExtra* extras, V3 ro, V3 rd
         // record costs a walk of one lane, and every shadow ray that passes ANY edge of a mesh within kGraze would leave one
         // (obj_mesh: 0.44 -> 1.45 ms for no pixel of its census; shapes_zoo keeps ONE pixel above 1e-4 for it,
         // profiles/r03_parity_census.txt): the plain test.
+#if RT_TRI_NEAR
+        default: {  // experiment: a crossing within kGraze (barycentric) of a triangle's edge, inside or outside
+            if (!EXOTIC) return false;
+            V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
+            const float* e = extras[p.extra].f;
+            bool occ = false;
+            const float w0 = amb_window(0.0f), w1 = amb_window(dist);
+            isect_triangle(
+                o, d, v3(e[0], e[1], e[2]), v3(e[3], e[4], e[5]), v3(e[6], e[7], e[8]),
+                [&](int slot, float t, float, float) { occ |= in_range(t, dist), near |= (slot & kUnsure) != 0 && in_win(t, -w0, dist + w1); },
+                [&](float t) { near |= in_win(t, -w0, dist + w1); });
+            return occ;
+        }
+#else
         default: return occludes_prim<EXOTIC>(p, extras, ro, rd, dist);
+#endif
     }
 }
 // ... and for the primitive the ray starts on: its own sphere grazed at the terminator (kUnsure roots, near misses)
