@@ -1587,39 +1587,64 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
     }
 
     if constexpr (kFix && (RT_FIX_PARTS & 2)) {
-        // The second count of the lights whose rays met a near thing: the wave takes its records one by one, lane after
-        // lane, each lane's from the last to the first (one order, whatever happens around the wave).  The record goes
-        // through an LDS row (the park rows are free now) to all 64 lanes, which count the light's cells, a cell a lane.
+        // The second count of the lights whose rays met a near thing.  A pass takes the light of the first waiting lane's
+        // newest record and, from every lane whose newest record is of that light, that record — up to kFixSlots of them,
+        // lower lanes first (one order, whatever happens around the wave).  They go through LDS rows (the park rows are
+        // free now) to slots of `width` lanes each, width = the light's cell count rounded up to a power of two: a slot
+        // counts its record's cells, a cell a lane.  (One record a pass, all 64 lanes on it, left 63 lanes idle for a point
+        // light: a tile with 27 records of obj_mesh's two point lights kept its wave 1.4 ms after the rest of the frame,
+        // profiles/r03_group_boxes.txt.)
+        constexpr uint32_t kFixSlots = 16;  // 16 records x 32 words = park rows 6..13 (rows 3..5 may hold the pixel sums)
         uint32_t n_mine = P.no_fix ? 0u : pend[0].scratch[0];
 #ifdef RT_PHASE_CLOCK
         const unsigned long long t_fix = __builtin_amdgcn_s_memtime();
 #endif
-        float* const ex = s_park + (threadIdx.x & ~63u) + 6 * kBlockThreads;  // 32 words of row 6 (rows 3..5 may hold the pixel sums)
+        float* const rows = s_park + (threadIdx.x & ~63u);
+        auto ex_at = [&](uint32_t slot_, uint32_t k) -> float& {
+            const uint32_t w = slot_ * 32u + k;
+            return rows[(6u + (w >> 6)) * kBlockThreads + (w & 63u)];
+        };
 #pragma unroll 1
         for (;;) {
             const unsigned long long mm = wave_ballot(n_mine != 0u);
             if (mm == 0ull) break;
-            const int src = __ffsll(static_cast<long long>(mm)) - 1;
+            const uint32_t my_light = n_mine != 0u ? (pend[(n_mine - 1u) < kPend ? n_mine - 1u : 0u].light & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+            const uint32_t li = rl_u(my_light, __ffsll(static_cast<long long>(mm)) - 1);
+            const bool light_ok = li < sc.n_lights;
+            const DLight l = sc.lights[light_ok ? li : 0u];
+            const XLight xl = args_here().sc.xlights[light_ok ? li : 0u];
+            const uint32_t cells = light_ok ? l.usteps * l.vsteps : 1u;
+            // width of a slot, log2: 0 for a point light .. 6 for 33 cells and more
+            const uint32_t wlog = cells >= 33u ? 6u : (cells <= 1u ? 0u : 32u - static_cast<uint32_t>(__clz(static_cast<int>(cells - 1u))));
+            const uint32_t width = 1u << wlog;
+            const uint32_t room = (64u >> wlog) < kFixSlots ? (64u >> wlog) : kFixSlots;
+            const unsigned long long same = wave_ballot(n_mine != 0u && my_light == li);
+            const uint32_t rank = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+            const uint32_t waiting = static_cast<uint32_t>(__popcll(same));
+            const uint32_t taken = waiting < room ? waiting : room;
 #ifdef RT_PHASE_CLOCK
-            ph[7]++;
+            ph[7] += taken;
 #endif
-            if (static_cast<int>(lane) == src) {
+            if (((same >> lane) & 1ull) != 0ull && rank < taken) {
                 --n_mine;
                 const FixRecord r = pend[n_mine < kPend ? n_mine : 0u];
                 const uint32_t* wds = reinterpret_cast<const uint32_t*>(&r);
-                for (int k = 0; k < 32; ++k) ex[k] = __uint_as_float(wds[k]);
+                for (uint32_t k = 0; k < 32u; ++k) ex_at(rank, k) = __uint_as_float(wds[k]);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            auto wd = [&](int k) { return uni(__float_as_uint(ex[k])); };
-            auto fl = [&](int k) { return __uint_as_float(wd(k)); };
-            auto db = [&](int k) {
-                return __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(wd(k)) | (static_cast<unsigned long long>(wd(k + 1)) << 32)));
+            const uint32_t slot = lane >> wlog, sub = lane & (width - 1u);
+            const bool on = slot < taken;
+            const uint32_t rs = on ? slot : 0u;
+            auto wd = [&](uint32_t k) { return __float_as_uint(ex_at(rs, k)); };
+            auto fl = [&](uint32_t k) { return ex_at(rs, k); };
+            auto db = [&](uint32_t k) {
+                return __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(wd(k)) | (static_cast<unsigned long long>(wd(k + 1u)) << 32)));
             };
-            const uint32_t pl = wd(0), li = wd(1) & 0x7FFFFFFFu, at_node = wd(2), key = wd(3), self_prim = wd(8);
+            const uint32_t pl = wd(0) & 63u, at_node = wd(2), key = wd(3), self_prim = wd(8);
             const bool was_refined = (wd(1) >> 31) != 0u;
             D3 over64 = d3(db(20), db(22), db(24));  // (a refined node's)
-            bool ok = li < sc.n_lights && self_prim < sc.n_items;
+            bool ok = on && light_ok && self_prim < sc.n_items;
 #ifdef RT_FIX_STUB  // experiment: the second count without its arithmetic (what the block's mere presence costs)
             ok = false;
 #endif
@@ -1638,55 +1663,55 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                 ok = xselect<EXOTIC>(ha, self_prim, p.type, ha, kNoPrim, REC_NODE, false, ft, pr, fu, fv);
                 if (ok) over64 = xprepare<EXOTIC>(p.type, xinv, args_here().sc.xextras[p.extra].f, ro, rd, ft, fu, fv).over;
             }
-            float delta = 0.0f;
-            if (ok) {
-                const DLight l = sc.lights[li];
-                const XLight xl = args_here().sc.xlights[li];
-                const uint32_t cells = l.usteps * l.vsteps;
-                const V3 o = to_v3(over64);
-                uint32_t lit = 0;
+            const V3 o = to_v3(over64);
+            const unsigned long long slot_mask = (wlog == 6u ? ~0ull : ((1ull << width) - 1ull)) << ((slot << wlog) & 63u);
+            uint32_t lit = 0;
 #pragma unroll 1
-                for (uint32_t c0 = 0; c0 < cells; c0 += 64u) {
-                    const uint32_t cell = c0 + lane;
-                    bool unocc = false;
-                    if (cell < cells) {
-                        V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
-                        D3 lp64 = d3(xl.pos[0], xl.pos[1], xl.pos[2]);
-                        if (l.type != RT_LIGHT_POINT) {  // light.rs:211-216
-                            const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
-                            float ju = 0.5f, jv = 0.5f;
-                            double ju64 = 0.5, jv64 = 0.5;
-                            if (P.jitter_mode == RT_JITTER_COUNTER) {
-                                counter_jitter(key, at_node, li, cell, ju, jv);
-                                xcounter_jitter(key, at_node, li, cell, ju64, jv64);
-                            }
-                            lp = point_on_light(l, cu, cv, ju, jv), lp64 = xpoint_on_light(xl, cu, cv, ju64, jv64);
+            for (uint32_t c0 = 0; c0 < cells; c0 += width) {
+                const uint32_t cell = c0 + sub;
+                bool unocc = false;
+                if (ok && cell < cells) {
+                    V3 lp = v3(l.pos[0], l.pos[1], l.pos[2]);
+                    D3 lp64 = d3(xl.pos[0], xl.pos[1], xl.pos[2]);
+                    if (l.type != RT_LIGHT_POINT) {  // light.rs:211-216
+                        const uint32_t cv = cell / l.usteps, cu = cell - cv * l.usteps;
+                        float ju = 0.5f, jv = 0.5f;
+                        double ju64 = 0.5, jv64 = 0.5;
+                        if (P.jitter_mode == RT_JITTER_COUNTER) {
+                            counter_jitter(key, at_node, li, cell, ju, jv);
+                            xcounter_jitter(key, at_node, li, cell, ju64, jv64);
                         }
-                        const V3 tl = lp - o;
-                        const float dist2 = dot(tl, tl);
-                        unocc = true;
-                        if (dist2 > 0.0f) {  // (a null vector is lit, world.rs:77-81: xoccludes decides that in f64)
-                            const float inv_dist = rsq_f(dist2);
-#ifdef RT_PHASE_CLOCK
-                            unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64, &ph[8]);
-#else
-                            unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
-#endif
-                        }
+                        lp = point_on_light(l, cu, cv, ju, jv), lp64 = xpoint_on_light(xl, cu, cv, ju64, jv64);
                     }
-                    lit += static_cast<uint32_t>(__popcll(wave_ballot(unocc)));
+                    const V3 tl = lp - o;
+                    const float dist2 = dot(tl, tl);
+                    unocc = true;
+                    if (dist2 > 0.0f) {  // (a null vector is lit, world.rs:77-81: xoccludes decides that in f64)
+                        const float inv_dist = rsq_f(dist2);
+#ifdef RT_PHASE_CLOCK
+                        unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64, &ph[8]);
+#else
+                        unocc = !fix_occluded<EXOTIC>(args_here().sc, self_prim, o, tl * inv_dist, dist2 * inv_dist, over64, lp64);
+#endif
+                    }
                 }
-                delta = static_cast<float>(lit) - fl(7);
+                lit += static_cast<uint32_t>(__popcll(wave_ballot(unocc) & slot_mask));
             }
+            const float delta = ok ? static_cast<float>(lit) - fl(7) : 0.0f;
             const V3 add = v3(fl(4), fl(5), fl(6)) * delta;
-            if (kSteal) {
-                if (static_cast<int>(lane) == src && delta != 0.0f) {
-                    atomicAdd(pixel_sum + 3 * kBlockThreads + pl, add.x);
-                    atomicAdd(pixel_sum + 4 * kBlockThreads + pl, add.y);
-                    atomicAdd(pixel_sum + 5 * kBlockThreads + pl, add.z);
+            // into the pixels, slot after slot: the lane of the record's pixel adds (with ray stealing: to its LDS sums)
+#pragma unroll 1
+            for (uint32_t s_ = 0; s_ < taken; ++s_) {
+                const int from = static_cast<int>(s_ << wlog);
+                const uint32_t to = rl_u(pl, from);
+                const V3 a = rl_v3(add, from);
+                if (lane == to && rl_f(delta, from) != 0.0f) {
+                    if (kSteal) {
+                        pixel_sum[3 * kBlockThreads + lane] += a.x, pixel_sum[4 * kBlockThreads + lane] += a.y, pixel_sum[5 * kBlockThreads + lane] += a.z;
+                    } else {
+                        acc = acc + a;
+                    }
                 }
-            } else if (lane == pl) {
-                acc = acc + add;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();

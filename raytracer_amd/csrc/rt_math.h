@@ -586,7 +586,8 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
 // within 1e-4 of another surface is known from the nearest-hit search: its second candidate).  One compare a sphere,
 // four instructions a cube.
 #ifndef RT_TRI_NEAR
-#define RT_TRI_NEAR 0  // experiment: triangle edges are near things for the shadow rays too (profiles/r03_group_boxes.txt)
+#define RT_TRI_NEAR 1  // triangle edges are near things for the shadow rays too: 7e-4 of obj_mesh's shadow rays leave a record,
+                       // +6 % of its frame since the second count takes 16 records a pass (3x before: profiles/r03_group_boxes.txt)
 #endif
 constexpr float kNearSphere = 2e-5f;
 template <bool EXOTIC = true>
@@ -620,12 +621,9 @@ RT_HD bool occludes_prim_near(const DPrim& p, const DExtra* extras, V3 ro, V3 rd
                 [&](float t) { near |= in_win(t, -w0, dist + w1); });
             return occ;
         }
-        // Planes have no near things of their own.  Triangles report none to the shadow rays: the second count of a
-        // record costs a walk of one lane, and every shadow ray that passes ANY edge of a mesh within kGraze would leave one
-        // (obj_mesh: 0.44 -> 1.45 ms for no pixel of its census; shapes_zoo keeps ONE pixel above 1e-4 for it,
-        // profiles/r03_parity_census.txt): the plain test.
+        case PRIM_PLANE: return occludes_prim<EXOTIC>(p, extras, ro, rd, dist);  // planes have no near things of their own
 #if RT_TRI_NEAR
-        default: {  // experiment: a crossing within kGraze (barycentric) of a triangle's edge, inside or outside
+        default: {  // triangles: a crossing within kGraze (barycentric) of an edge, inside or outside
             if (!EXOTIC) return false;
             V3 o = xform_point(p.inv, ro), d = xform_vector(p.inv, rd);
             const float* e = extras[p.extra].f;

@@ -1,11 +1,11 @@
 """Near things outside the sphere/cube/plane family (round 3): pixels of the FULL-SIZE shapes_zoo frame that were more
 than 1e-4 from the f64 oracle until the kinds of near thing they hang on were handed to the f64 chain
-(profiles/r03_parity_census.txt; the one left, (856, 777), is a shadow ray past a triangle's edge, not
-handed over on purpose: rt_math.h occludes_prim_near):
+(profiles/r03_parity_census.txt):
   a ray grazing a cylinder's wall or crossing it at a rim             rt_math.h isect_cylinder (kUnsure / soft)
   a cylinder WALL point that got an end's normal (cylinder.rs:172-184) rt_exact.h xprepare: qedge
   a Group's box clipped within FP32 reach of an edge (group.rs:107)    rt_math.h gates_pass_near, rt_exact.h xgates_pass,
                                                                        rt_scene_desc.node_box64
+  a shadow ray past a triangle's edge                                  rt_math.h occludes_prim_near
 The scalar spec (tests/cpp/hostsim.cpp) is checked here on the CPU; the kernels on the GPU against the same colours."""
 import ctypes as C
 
@@ -17,7 +17,7 @@ from raytracer_amd import ExampleScene, RtOptions
 
 W, Hh = 1920, 1080
 # (x, y, jitter mode): the outliers of the round-2 and first round-3 censuses of shapes_zoo, centre and counter jitter
-PIXELS = [(562, 206, 0), (967, 558, 0), (1424, 727, 0), (1489, 801, 0), (1249, 952, 0), (1472, 956, 0),
+PIXELS = [(562, 206, 0), (967, 558, 0), (1424, 727, 0), (856, 777, 0), (1489, 801, 0), (1249, 952, 0), (1472, 956, 0),
           (1260, 962, 0), (562, 206, 1), (1267, 523, 1), (1424, 727, 1), (1489, 801, 1), (1472, 956, 1), (1264, 984, 1),
           (1269, 999, 1)]
 
