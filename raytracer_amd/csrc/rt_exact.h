@@ -369,6 +369,9 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
                 nobj = d3(0.0, 0.0, p.z), h.qedge = !(fabs(az - 1.0) <= kOnFace);
                 if (!h.qedge) h.qobj.z = p.z < 0.0 ? -1.0 : 1.0;
             }
+            // ... and a point ON an edge line (two coordinates at +-1 to rounding: the far end of the room's floor, where it
+            // meets the wall) stands 1e-15 inside or outside the OTHER face: the same noise decides what leaves it.
+            if ((fabs(ax - 1.0) <= kOnFace) + (fabs(ay - 1.0) <= kOnFace) + (fabs(az - 1.0) <= kOnFace) >= 2) h.qedge = true;
             break;
         }
         case PRIM_CYLINDER: {  // cylinder.rs:172-184

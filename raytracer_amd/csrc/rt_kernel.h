@@ -760,6 +760,11 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         uint32_t alt_prim = kNoPrim, excl0 = kNoPrim, excl1 = kNoPrim;
         float alt_t = INFINITY;
         double t64 = 0.0, u64 = 0.0, v64 = 0.0;
+        // EXACT: the ray leaves a point where the reference's rounding noise decides whether it meets the primitive it stands
+        // on again at t ~ 1e-15 (XHit::qedge of its parent node, handed down in dq: rt_math.h with_noise_flag).  f64 is asked
+        // about that primitive first: a crossing within 1e-9 of the start is the hit (random_stress:180, random_field:113,
+        // random_stress:39); anything else, and the search runs again.
+        [[maybe_unused]] const bool self_noise = EXACT && active && cur.self != kNoPrim && noise_flag(cur.dq.x);
         // (The search and the f64 selection are two calls each, the second one rare.)
         auto do_trace = [&](bool live) {
             auto trace_enter = [&](uint32_t, const auto& nd) {
@@ -822,12 +827,13 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     hb = xintersect<EXOTIC>(pb.type, args_here().sc.xprims[second].inv, args_here().sc.xextras[pb.extra].f, r.o, r.d);
                 }
                 uint32_t pr = kNoPrim;
-                if (xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64)) {
+                if (xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
+                    !(may_retry && self_noise && !(t64 < 1e-9))) {
                     refined = true;
                     hit_prim = pr, hit_t = static_cast<float>(t64), hit_u = static_cast<float>(u64), hit_v = static_cast<float>(v64);
                 } else {
                     retry = may_retry;
-                    excl0 = a, excl1 = b;
+                    excl0 = self_noise ? kNoPrim : a, excl1 = self_noise ? kNoPrim : b;  // (self_noise: the primitive's far side may be the hit)
                     hit_prim = kNoPrim, hit_t = INFINITY, alt_prim = kNoPrim, alt_t = INFINITY, hit_unsure = false;
                 }
             }
@@ -850,6 +856,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     if (gate_out) excl0 = hit_prim, hit_prim = kNoPrim, hit_t = INFINITY, alt_prim = kNoPrim, alt_t = INFINITY, hit_unsure = false;
                 }
             }
+            if (self_noise && !gate_out) hit_prim = cur.self, hit_t = 0.0f, hit_u = 0.0f, hit_v = 0.0f, hit_unsure = true, alt_prim = kNoPrim, alt_t = INFINITY;
             const bool retry = do_select(active && !gate_out, true) || gate_out;
             if (wave_any(retry)) {  // rare: a grazing FP32 hit that f64 does not confirm, a winner its Group hides
                 do_trace(retry);
@@ -1010,6 +1017,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
         park[8 * kBlockThreads] = pc.x, park[9 * kBlockThreads] = pc.y, park[10 * kBlockThreads] = pc.z;
         park[11 * kBlockThreads] = m_ambient, park[12 * kBlockThreads] = m_diffuse, park[13 * kBlockThreads] = m_specular;
         park[14 * kBlockThreads] = 0.0f, park[15 * kBlockThreads] = 0.0f, park[16 * kBlockThreads] = 0.0f;  // surface colour so far
+        if constexpr (EXACT) hdq.x = with_noise_flag(hdq.x, qedge);  // (for the rays that leave this point: "self_noise")
         if (AREA) {
             park[24 * kBlockThreads] = over.x, park[25 * kBlockThreads] = over.y, park[26 * kBlockThreads] = over.z;
             park[27 * kBlockThreads] = hq.x, park[28 * kBlockThreads] = hq.y, park[29 * kBlockThreads] = hq.z;

@@ -654,6 +654,24 @@ RT_HD bool occludes_self_near(const DPrim& p, const DExtra* extras, const Ray& r
     return hit;
 }
 
+// A path ray that leaves a point where the reference's own rounding noise decides whether it meets the primitive it stands
+// on AGAIN, at t ~ 1e-15 (rt_exact.h XHit::qedge: a cube's point on an edge line or with the neighbouring face's normal, a
+// cylinder's wall point with an end's normal), says so to its own first search through the lowest mantissa bit of
+// dq.x — 1e-12 of an offset of 1e-5, and no register, stack word or record load for it (deriving it again from q and dq
+// took sheared cubes for noise: shapes_zoo +5 %).  The f64 chain then asks the primitive itself (rt_kernel.h "self_noise").
+RT_HD float with_noise_flag(float dq_x, bool noise) {
+    uint32_t b;
+    __builtin_memcpy(&b, &dq_x, 4);
+    b = (b & ~1u) | (noise ? 1u : 0u);
+    __builtin_memcpy(&dq_x, &b, 4);
+    return dq_x;
+}
+RT_HD bool noise_flag(float dq_x) {
+    uint32_t b;
+    __builtin_memcpy(&b, &dq_x, 4);
+    return (b & 1u) != 0u;
+}
+
 // What FP32 cannot settle about a shadow ray (the exact chain decides it in f64: rt_exact.h xoccludes, rt_kernel.h
 // "unsure shadow rays").  The any-hit question has three kinds of near things: a ray GRAZING a sphere or the edge of
 // a cube (kGraze, object units), a crossing within w0 of the ray's ORIGIN (the point stands within 1e-5 .. 1e-4 of

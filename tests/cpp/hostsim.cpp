@@ -121,9 +121,7 @@ bool occluded_near(const Sim& s, const Ray& ray, float dist, bool& near) {
         bool hit;
         if (prim == ray.self) hit = occludes_self_near(p, s.ps.extras.data(), ray, dist, near);
         else hit = occludes_prim_near(p, s.ps.extras.data(), ray.o, ray.d, dist, near);
-        { bool n0 = near; occ = hit && gated_in_near_first_pass(s, prim, ray.o, ray.d, near);
-          static const bool dbg = getenv("RT_DBG") != nullptr;
-          if (dbg) fprintf(stderr, "DBG sh prim %u type %u self %d hit %d occ %d near %d->%d dist %.7g o (%.8g %.8g %.8g) d (%.8g %.8g %.8g)\n", prim, p.type, (int)(prim == ray.self), (int)hit, (int)occ, (int)n0, (int)near, dist, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z); }
+        occ = hit && gated_in_near_first_pass(s, prim, ray.o, ray.d, near);
         return !occ;
     });
     return occ;
@@ -362,6 +360,11 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
         bool alive = false;
         // ---- nearest hit: FP32 search; the exact chain settles what FP32 cannot and refines what matters
         Closest c = closest_hit(s, cur.ray);
+        // A ray that leaves a point where rounding noise decides whether it meets its own primitive again (rt_math.h
+        // with_noise_flag, set by the parent node): f64 is asked about the primitive itself first; a crossing within 1e-9 of the start is the hit
+        // (rt_kernel.h "self_noise"), anything else and the search runs again.
+        const bool self_noise = s.exact && cur.ray.self != kNoPrim && noise_flag(cur.ray.dq.x);
+
         if (g_tie_audit && c.prim != kNoPrim) {
             const Closest f = closest_hit_fixed_window(s, cur.ray);
             g_tie_hits += 1, g_tie_differs += (f.prim != c.prim) ? 1u : 0u, g_tie_wide_used += (tie_window(c.t) > kEps) ? 1u : 0u;
@@ -388,6 +391,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                         attempt = 1;
                     }
                 }
+                if (attempt == 0 && self_noise) c = Closest{cur.ray.self, 0.0f, 0.0f, 0.0f}, c.unsure = true;
                 bool amb = c.unsure || c.alt != kNoPrim;
                 bool why_children = false;
                 const bool why_pattern = false, why_edge = false;
@@ -409,7 +413,8 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     hb = xintersect(pb.type, s.ps.xprims[second].inv, s.ps.xextras[pb.extra].f, cur.o64, cur.d64);
                 }
                 uint32_t pr = kNoPrim;
-                if (xselect<true>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64)) {
+                if (xselect<true>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
+                    !(self_noise && attempt == 0 && !(t64 < 1e-9))) {
                     g_x_refined += 1, g_x_children += why_children, g_x_pattern += why_pattern, g_x_amb += amb, g_x_edge += why_edge;
                     g_x_changed += (pr != c.prim) ? 1u : 0u;
                     refined = true;
@@ -420,7 +425,8 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                 g_x_retry += 1;
                 hit_prim = kNoPrim;
                 if (attempt == 1) break;
-                c = closest_hit(s, cur.ray, a, b);
+                if (self_noise) c = closest_hit(s, cur.ray);  // (nothing is left out: the primitive's far side may be the hit)
+                else c = closest_hit(s, cur.ray, a, b);
                 hit_prim = c.prim, hit_t = c.t, hit_u = c.u, hit_v = c.v;
             }
         }
@@ -449,6 +455,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                 const V3 ca = v3(pat.a[0], pat.a[1], pat.a[2]), cb = v3(pat.b[0], pat.b[1], pat.b[2]);
                 pc = pat.type == PAT_GRADIENT ? ca + (cb - ca) * static_cast<float>(frac) : (is_a ? ca : cb);
             }
+            if (s.exact) h.dq.x = with_noise_flag(h.dq.x, refined && xh.qedge);  // (for the rays that leave this point)
             V3 surface = v3(0, 0, 0);
             double lit_by_light[4] = {-1.0, -1.0, -1.0, -1.0};
             for (uint32_t li = 0; li < s.ps.n_lights; ++li) {
@@ -481,7 +488,6 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     phong_cell(phong_point(over, h.n, h.eye, m.shininess), centre, ldn, spec);
                     sum_d += ldn, sum_s += spec;
                 }
-                { static const bool dbg = getenv("RT_DBG") != nullptr; if (dbg) fprintf(stderr, "DBG node %u light %u lit %u near_any %d refined %d qedge %d hit_prim %u\n", cur.node, li, lit, (int)near_any, (int)refined, (int)(refined && xh.qedge), hit_prim); }
                 if (s.exact && (near_any || (refined && xh.qedge))) {
                     // rt_kernel.h "unsure shadow rays": a FixRecord, and the fix kernel counts this light's cells again
                     g_sh_redo += 1, g_sh_why_near += near_any, g_sh_why_qedge += refined && xh.qedge;
