@@ -1275,7 +1275,6 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     need &= ~__ballot(dark || open || umbra);
                 }
                 n_visibility += static_cast<uint32_t>(__popcll(need)) * chunks;  // (counted whether or not a cost table asks: no pointer to keep)
-                [[maybe_unused]] const unsigned long long cast_mask = need;  // the lanes whose point casts rays towards this light
 
                 if (RT_EXP & 1024) need = 0;
                 // A tile with many such points (it lies in a penumbra): every lane casts its OWN
@@ -1424,7 +1423,10 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     if (owner_now) lit = static_cast<float>(my_lit);
                     if constexpr (EXACT) fix_li |= owner_now && owner_unsure;
                 }
-                if constexpr (EXACT) emit_fix(fix_li || (qedge && ((cast_mask >> lane) & 1ull) != 0ull), li, lit, sum_d, sum_s, lc, l.inv_samples);
+                // (a qedge point also when its shaft was found empty or wholly blocked and nothing was cast: the shaft tests
+                // reason about the point OUTSIDE its own convex body, and this one stands 1e-15 inside — the corner line of
+                // cover_image_area's room, lit by the tests and shadowed by its own face in the reference)
+                if constexpr (EXACT) emit_fix(fix_li || (qedge && shades && (sum_d != 0.0f || sum_s != 0.0f)), li, lit, sum_d, sum_s, lc, l.inv_samples);
                 lit *= l.inv_samples;  // light.rs:208
             }
             if (has_hit) {  // material.rs:127-161
