@@ -76,3 +76,37 @@ def test_kernels_follow_the_reference_at_the_former_outliers(jitter):
         sc.close()
     err = np.abs(img[xy[:, 1], xy[:, 0]].astype(np.float64) - want).max(axis=1)
     assert (err <= 1e-4).all() and st.exact_nodes > 0, list(zip(xy.tolist(), err.tolist()))
+
+
+# cover_image_area's last four census pixels (profiles/r03_parity_census.txt): points on the corner line of the room's cube,
+# 1e-15 inside the face next to theirs — dark in the reference, whose shadow rays leave through that face at t ~ 1e-15.
+ROOM_CORNER = np.array([(1497, 416), (2627, 1126), (2694, 1411), (2558, 1862)], dtype=np.int32)
+
+
+def test_scalar_spec_follows_the_reference_on_the_rooms_corner_line():
+    want = H.oracle_probe("cover_image_area", 3840, 2160, ROOM_CORNER)
+    S = H.hostsim()
+    S.hostsim_trace_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    ex = ExampleScene("cover_image_area", 3840, 2160)
+    opt = RtOptions()
+    n, cap = len(ROOM_CORNER), 64
+    ev = np.zeros((n, cap, 24))
+    cnt = np.zeros(n, dtype=np.int32)
+    rgb = np.zeros((n, 3), dtype=np.float32)
+    assert S.hostsim_trace_pixels(C.cast(ex.scene_desc, C.c_void_p), C.cast(ex.camera_desc, C.c_void_p), C.cast(C.byref(opt), C.c_void_p),
+                                  ROOM_CORNER.ctypes.data, n, ev.ctypes.data, cap, cnt.ctypes.data, rgb.ctypes.data) == 0
+    assert np.abs(rgb.astype(np.float64) - want).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_kernels_follow_the_reference_on_the_rooms_corner_line():
+    from raytracer_amd import Scene
+    want = H.oracle_probe("cover_image_area", 3840, 2160, ROOM_CORNER)
+    ex = ExampleScene("cover_image_area", 3840, 2160)
+    sc = Scene(ex.scene_desc, 0)
+    try:
+        img, _ = sc.render(ex.camera_desc, RtOptions())
+    finally:
+        sc.close()
+    err = np.abs(img[ROOM_CORNER[:, 1], ROOM_CORNER[:, 0]].astype(np.float64) - want).max(axis=1)
+    assert (err <= 1e-4).all(), err
