@@ -410,7 +410,8 @@ __device__ __forceinline__ void traverse(const KScene& sc, uint32_t self_prim, b
 
 // world.rs:73-92 as an any-hit query: occluded iff some intersection lies in (0, dist).
 // NEAR (the kernels with the f64 chain): `unsure` also reports whether some test on the way was a near thing — a grazed
-// sphere or cube edge, the own sphere at the terminator (rt_math.h occludes_prim_near): this light's count at this node
+// sphere, cube edge, cylinder wall or rim, triangle edge, a Group's box clipped at a corner, the own sphere at the
+// terminator (rt_math.h occludes_prim_near, gates_pass_near): this light's count at this node
 // is then worked out again by the fix kernel.
 template <bool EXOTIC, bool TREE, int LANE, bool NEAR>
 __device__ __forceinline__ bool occluded(const KScene& sc, const Ray& ray, float dist, bool live, bool masked, unsigned long long mask, bool& unsure) {

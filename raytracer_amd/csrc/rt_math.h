@@ -582,9 +582,10 @@ RT_HD bool occludes_prim(const DPrim& p, const DExtra* extras, V3 ro, V3 rd, flo
 }
 
 // The hot form of the question below, for the FIRST pass of the kernels with the f64 chain: the plain answer, plus
-// `near` = the ray grazes this sphere or the edge of this cube (the two near things a point in the open meets; a point
-// within 1e-4 of another surface is known from the nearest-hit search: its second candidate).  One compare a sphere,
-// four instructions a cube.
+// `near` = the ray grazes this sphere, the edge of this cube, the wall or a rim of this cylinder, an edge of this triangle
+// (the near things a point in the open meets; a point within 1e-4 of another surface is known from the nearest-hit
+// search: its second candidate).  One compare a sphere, four instructions a cube; cylinders and triangles go through
+// their emitters (kUnsure / soft), in the kernels compiled for them only.
 #ifndef RT_TRI_NEAR
 #define RT_TRI_NEAR 1  // triangle edges are near things for the shadow rays too: 7e-4 of obj_mesh's shadow rays leave a record,
                        // +6 % of its frame since the second count takes 16 records a pass (3x before: profiles/r03_group_boxes.txt)

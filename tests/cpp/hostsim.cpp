@@ -112,7 +112,8 @@ bool occluded(const Sim& s, const Ray& ray, float dist) {
     return occ;
 }
 // The same with the exact chain (rt_kernel.h "unsure shadow rays").  The render kernel's walk: the plain answer, and
-// `near` = some test on the way was a near thing (a grazed sphere or cube edge, the own sphere at the terminator).
+// `near` = some test on the way was a near thing (a grazed sphere, cube edge, cylinder wall or rim, triangle edge, a Group's
+// box clipped at a corner, the own sphere at the terminator).
 std::atomic<uint64_t> g_sh_rays{0}, g_sh_unsure{0}, g_sh_f64{0}, g_sh_redo{0}, g_sh_why_qedge{0}, g_sh_why_near{0};
 bool occluded_near(const Sim& s, const Ray& ray, float dist, bool& near) {
     bool occ = false;
