@@ -838,6 +838,28 @@ inline int pack_scene(const rt_scene_desc* d, PackedScene& out, std::string& err
                 box[k] = prim_world_box(d->prim_type[ref], d->prim_inv + 12 * ref, d->prim_param ? d->prim_param + 24 * ref : nullptr);
             }
         });
+        // A primitive strictly inside the box of every Group around it needs no gate: a line that meets it anywhere runs
+        // through the interior of those boxes, tmin < tmax (group.rs:107) holds in the reference and here.  What keeps its
+        // gates: the few primitives a Group's box is drawn around (they touch it), unbounded ones, and primitives that lie
+        // OUTSIDE the boxes around them (shapes_zoo's cube, profiles/r03_group_boxes.txt).
+        if (out.has_gates) {
+            parallel_chunks(box.size(), 1u << 14, [&](unsigned, size_t lo, size_t hi) {
+                for (size_t k = lo; k < hi; ++k) {
+                    if (!box[k].bounded) continue;
+                    bool inside = true;
+                    for (uint32_t g = item_gate[prim_items[k]]; g != kNoGate && inside; g = out.gates[g].parent) {
+                        const XGate& xg = out.xgates[g];
+                        for (int c = 0; c < 3; ++c) {
+                            const double m = 1e-5 * (1.0 + std::fabs(box[k].mn[c]) + std::fabs(box[k].mx[c]));
+                            inside = inside && xg.mn[c] + m < box[k].mn[c] && box[k].mx[c] + m < xg.mx[c];
+                        }
+                    }
+                    if (inside) item_gate[prim_items[k]] = kNoGate;
+                }
+            });
+            out.has_gates = false;
+            for (uint32_t item : prim_items) out.has_gates |= item_gate[item] != kNoGate;
+        }
         size_t n_bounded = 0;
         for (const HostBox& x : box) n_bounded += x.bounded ? 1 : 0;
         if (flat || n_bounded <= 2) {
