@@ -903,6 +903,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
             const uint32_t ord_hit = (TREE && has_hit) ? sc.order[hit_prim] : hit_prim;
             const V3 hp = madd(cur.d, hit_t, cur.o);
             const float hm = container_margin(hit_t, hp);
+            [[maybe_unused]] const float amb_w = container_amb_window(hit_t, fabsf(dot(nrm, cur.d)));  // EXACT: what FP32 cannot order against the hit
             traverse<TREE, kLane, false>(
                 sc, cur.self, need_n, cur.d,
                 [&](uint32_t, const auto& nd) {
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     // EXACT: the first primitive with a crossing FP32 cannot order against the hit waits for f64
                     // (if constexpr: the other kernels' visitor must not even capture what this reads)
                     if constexpr (EXACT && RT_CONTAINER_F64 != 0) {
-                        if (any && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(hh, hit_t)) amb_prim = prim, any = false;
+                        if (any && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(hh, hit_t, amb_w)) amb_prim = prim, any = false;
                     }
                     if (any) cs.add(hh, prim == hit_prim, TREE ? sc.order[prim] : prim, p.ior, ord_hit, hit_t, prim);
                     return true;

@@ -1056,9 +1056,16 @@ RT_HD int shaft_side_of_surface(const Shaft& s, V3 n, const DLight& l) {
 // EXACT: a crossing of ANOTHER primitive this close to the hit is more than FP32 can order against the reference's
 // 1e-5 rule: a ray that grazes the face two stacked cubes share gets t = (1 - o_k) / d_k to 1e-7 / |d_k| only
 // (1.2e-5 at t = 0.58 in random_stress:148).  The kernel then places that primitive's crossings in f64 (rt_exact.h).
-RT_HD float container_amb_window(float t) { return 16.0f * tie_window(t); }
-RT_HD bool crossing_near_hit(const Hits& h, float t_hit) {
-    const float w = container_amb_window(t_hit);
+// (... and 2e-4 at t = 0.3 in random_stress:41, where the ray meets the shared face at 1e-3 rad: the window grows with
+// 1 / |n . d| of the hit, `cos_hit`.)
+#ifndef RT_AMB_GRAZE
+#define RT_AMB_GRAZE 1  // experiments: 0 = the fixed window of round 2
+#endif
+RT_HD float container_amb_window(float t, float cos_hit) {
+    if (!RT_AMB_GRAZE) return 16.0f * tie_window(t);
+    return 16.0f * tie_window(t) * fminf(fmaxf(0.02f * rcp_f(fmaxf(cos_hit, 1e-6f)), 1.0f), 256.0f);
+}
+RT_HD bool crossing_near_hit(const Hits& h, float t_hit, float w) {
     return fabsf(h.t[0] - t_hit) <= w || fabsf(h.t[1] - t_hit) <= w || fabsf(h.t[2] - t_hit) <= w || fabsf(h.t[3] - t_hit) <= w;  // NaN: false
 }
 #ifndef RT_CONTAINER_TIES

@@ -154,8 +154,9 @@ bool occluded_fix(const Sim& s, uint32_t self_prim, V3 o, V3 d, float dist, D3 o
 // odd number of its intersections precede the hit; `visited.last()` is the container whose last
 // crossing before the hit has the largest t.
 void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, float hit_ior, float& n1, float& n2, uint32_t& n1_prim,
-                uint32_t& n2_prim, bool refined = false, double t64 = 0.0, D3 o64 = D3{0, 0, 0}, D3 d64 = D3{0, 0, 0}) {
+                uint32_t& n2_prim, bool refined = false, double t64 = 0.0, D3 o64 = D3{0, 0, 0}, D3 d64 = D3{0, 0, 0}, float cos_hit = 1.0f) {
     uint32_t amb_prim = kNoPrim;
+    const float amb_w = container_amb_window(t_hit, cos_hit);
     ContainerScan cs;
     cs.order = s.ps.order.data();
     const V3 hp = madd(ray.d, t_hit, ray.o);
@@ -175,7 +176,7 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
         intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot & 3] = t, any = true; });
         if (any && gated_in(s, prim, ray)) {
             // the kernel's rule: the first primitive with a crossing FP32 cannot order against the hit waits for f64
-            if (s.exact && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(h, t_hit)) amb_prim = prim;
+            if (s.exact && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(h, t_hit, amb_w)) amb_prim = prim;
             else cs.add(h, prim == hit_prim, s.ps.order[prim], p.ior, s.ps.order[hit_prim], t_hit, prim);
         }
     }
@@ -545,7 +546,7 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
             float n1 = 1.0f, n2 = 1.0f;
             uint32_t n1_prim = kNoPrim, n2_prim = kNoPrim;
             bool use_schlick = (m.reflectivity * m.transparency) > 0.0f;
-            if (cur.depth > 0 && m.transparency > 0.0f) containers(s, cur.ray, hit_prim, hit_t, m.ior, n1, n2, n1_prim, n2_prim, refined, t64, cur.o64, cur.d64);
+            if (cur.depth > 0 && m.transparency > 0.0f) containers(s, cur.ray, hit_prim, hit_t, m.ior, n1, n2, n1_prim, n2_prim, refined, t64, cur.o64, cur.d64, fabsf(dot(h.n, cur.ray.d)));
             if (debug) std::printf("        n1=%.6g n2=%.6g\n", n1, n2);
             V3 rdir = v3(0, 0, 0);
             D3 rdir64 = d3(0, 0, 0);
