@@ -915,7 +915,16 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     Hits hh;
                     hh.t[0] = hh.t[1] = hh.t[2] = hh.t[3] = RT_NOHIT;
                     bool any = false;
-                    intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, [&](int slot, float t, float, float) { hh.t[slot & 3] = t, any = true; });
+                    auto crossing = [&](int slot, float t, float, float) { hh.t[slot & 3] = t, any = true; };
+                    if constexpr (EXOTIC && decltype(self)::value) {
+                        // the triangle the ray starts on: its crossing behind the origin counts (the ray is inside the mesh)
+                        // also when FP32 puts it a hair past an edge — the parent's hit on it stood (random_mesh:107)
+                        intersect_prim<EXOTIC>(p, sc.extras, cur, true, crossing, [&](float t) {
+                            if (p.type >= PRIM_TRIANGLE) hh.t[0] = t, any = true;
+                        });
+                    } else {
+                        intersect_prim<EXOTIC>(p, sc.extras, cur, decltype(self)::value, crossing);
+                    }
                     if (any && (TREE && sc.has_gates)) any = gates_pass(sc.gates, sc.gate[prim], cur.o, cur.d);
                     // EXACT: the first primitive with a crossing FP32 cannot order against the hit waits for f64
                     // (if constexpr: the other kernels' visitor must not even capture what this reads)

@@ -173,7 +173,11 @@ void containers(const Sim& s, const Ray& ray, uint32_t hit_prim, float t_hit, fl
         Hits h;
         h.t[0] = h.t[1] = h.t[2] = h.t[3] = RT_NOHIT;
         bool any = false;
-        intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, [&](int slot, float t, float, float) { h.t[slot & 3] = t, any = true; });
+        auto crossing = [&](int slot, float t, float, float) { h.t[slot & 3] = t, any = true; };
+        if (s.ps.exotic && ray.self == prim)  // (rt_kernel.h: the triangle the ray starts on, a hair past its edge in FP32)
+            intersect_prim(p, s.ps.extras.data(), ray, true, crossing, [&](float t) { if (p.type >= PRIM_TRIANGLE) h.t[0] = t, any = true; });
+        else
+            intersect_prim(p, s.ps.extras.data(), ray, ray.self == prim, crossing);
         if (any && gated_in(s, prim, ray)) {
             // the kernel's rule: the first primitive with a crossing FP32 cannot order against the hit waits for f64
             if (s.exact && refined && prim != hit_prim && amb_prim == kNoPrim && crossing_near_hit(h, t_hit, amb_w)) amb_prim = prim;
