@@ -828,13 +828,19 @@ __global__ __launch_bounds__(kBlockThreads, min_blocks_of(EXOTIC, TREE, AREA, EX
                     hb = xintersect<EXOTIC>(pb.type, args_here().sc.xprims[second].inv, args_here().sc.xextras[pb.extra].f, r.o, r.d);
                 }
                 uint32_t pr = kNoPrim;
-                if (xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
-                    !(may_retry && self_noise && !(t64 < 1e-9))) {
+                // (EXOTIC) a near miss in FRONT of the winner that f64 does not confirm may hide another: a ray through the edge
+                // two triangles share can be a hair outside BOTH in FP32, and one candidate is all the search keeps
+                // (random_mesh:2).  The search then runs again without the one f64 has cleared.
+                const bool alt_front = EXOTIC && may_retry && a != kNoPrim && b != kNoPrim && a != b && alt_t < hit_t - amb_window(hit_t);  // (a == b: a cylinder's rim reported before its cap was hit)
+                const bool found = xselect<EXOTIC>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
+                                   !(may_retry && self_noise && !(t64 < 1e-9));
+                const bool hidden = found && alt_front && pr == a;
+                if (found && !hidden) {
                     refined = true;
                     hit_prim = pr, hit_t = static_cast<float>(t64), hit_u = static_cast<float>(u64), hit_v = static_cast<float>(v64);
                 } else {
                     retry = may_retry;
-                    excl0 = self_noise ? kNoPrim : a, excl1 = self_noise ? kNoPrim : b;  // (self_noise: the primitive's far side may be the hit)
+                    excl0 = hidden ? b : (self_noise ? kNoPrim : a), excl1 = (hidden || self_noise) ? kNoPrim : b;  // (self_noise: the primitive's far side may be the hit)
                     hit_prim = kNoPrim, hit_t = INFINITY, alt_prim = kNoPrim, alt_t = INFINITY, hit_unsure = false;
                 }
             }

@@ -419,8 +419,12 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                     hb = xintersect(pb.type, s.ps.xprims[second].inv, s.ps.xextras[pb.extra].f, cur.o64, cur.d64);
                 }
                 uint32_t pr = kNoPrim;
-                if (xselect<true>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
-                    !(self_noise && attempt == 0 && !(t64 < 1e-9))) {
+                // (rt_kernel.h "hidden": a near miss in front of the winner that f64 clears may hide another one)
+                const bool alt_front = s.ps.exotic && attempt == 0 && a != kNoPrim && b != kNoPrim && a != b && c.alt_t < c.t - amb_window(c.t);
+                const bool found = xselect<true>(ha, first, pa.type, hb, second, type_b, second != kNoPrim, t64, pr, u64, v64) &&
+                                   !(self_noise && attempt == 0 && !(t64 < 1e-9));
+                const bool hidden = found && alt_front && pr == a;
+                if (found && !hidden) {
                     g_x_refined += 1, g_x_children += why_children, g_x_pattern += why_pattern, g_x_amb += amb, g_x_edge += why_edge;
                     g_x_changed += (pr != c.prim) ? 1u : 0u;
                     refined = true;
@@ -431,7 +435,8 @@ V3 trace_pixel(const Sim& s, uint32_t x, uint32_t y, bool debug = false, std::ve
                 g_x_retry += 1;
                 hit_prim = kNoPrim;
                 if (attempt == 1) break;
-                if (self_noise) c = closest_hit(s, cur.ray);  // (nothing is left out: the primitive's far side may be the hit)
+                if (hidden) c = closest_hit(s, cur.ray, b, kNoPrim);
+                else if (self_noise) c = closest_hit(s, cur.ray);  // (nothing is left out: the primitive's far side may be the hit)
                 else c = closest_hit(s, cur.ray, a, b);
                 hit_prim = c.prim, hit_t = c.t, hit_u = c.u, hit_v = c.v;
             }
