@@ -110,3 +110,44 @@ def test_kernels_follow_the_reference_on_the_rooms_corner_line():
         sc.close()
     err = np.abs(img[ROOM_CORNER[:, 1], ROOM_CORNER[:, 0]].astype(np.float64) - want).max(axis=1)
     assert (err <= 1e-4).all(), err
+
+
+# Pixels of the seeded fuzz families (160x96, centre jitter) that were above 1e-4 at some point of round 3 and what closed
+# them (profiles/r03_group_boxes.txt): the whole f64 over point in the records of the second count (field:98, stress:169),
+# triangle edges for the shadow rays (mesh:102, mesh:130), path rays that leave a noise point (field:113, field:134,
+# stress:39, stress:162, stress:180, stress:189), the container window at grazing hits (stress:41), the triangle a ray starts
+# on as its container (mesh:107), a near miss that hid another one (mesh:2).
+FUZZ = [("random_field:98", 107, 51), ("random_stress:169", 40, 59), ("random_mesh:102", 88, 54), ("random_mesh:130", 79, 78),
+        ("random_field:113", 142, 44), ("random_field:134", 156, 53), ("random_stress:39", 62, 64), ("random_stress:162", 152, 73),
+        ("random_stress:180", 51, 71), ("random_stress:189", 67, 25), ("random_stress:41", 18, 64), ("random_mesh:107", 33, 69),
+        ("random_mesh:2", 31, 53)]
+
+
+@pytest.mark.parametrize("name,x,y", FUZZ)
+def test_scalar_spec_follows_the_reference_at_former_fuzz_outliers(name, x, y):
+    xy = np.array([(x, y)], dtype=np.int32)
+    want = H.oracle_probe(name, 160, 96, xy)
+    S = H.hostsim()
+    S.hostsim_trace_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    ex = ExampleScene(name, 160, 96)
+    opt = RtOptions()
+    ev = np.zeros((1, 64, 24))
+    cnt = np.zeros(1, dtype=np.int32)
+    rgb = np.zeros((1, 3), dtype=np.float32)
+    assert S.hostsim_trace_pixels(C.cast(ex.scene_desc, C.c_void_p), C.cast(ex.camera_desc, C.c_void_p), C.cast(C.byref(opt), C.c_void_p),
+                                  xy.ctypes.data, 1, ev.ctypes.data, 64, cnt.ctypes.data, rgb.ctypes.data) == 0
+    assert np.abs(rgb[0].astype(np.float64) - want[0]).max() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,x,y", FUZZ)
+def test_kernels_follow_the_reference_at_former_fuzz_outliers(name, x, y):
+    from raytracer_amd import Scene
+    want = H.oracle_probe(name, 160, 96, np.array([(x, y)], dtype=np.int32))
+    ex = ExampleScene(name, 160, 96)
+    sc = Scene(ex.scene_desc, 0)
+    try:
+        img, _ = sc.render(ex.camera_desc, RtOptions())
+    finally:
+        sc.close()
+    assert np.abs(img[y, x].astype(np.float64) - want[0]).max() <= 1e-4
