@@ -388,6 +388,10 @@ RT_HD XHit xprepare(uint32_t type, const double* inv, const double* e, D3 ro, D3
             if (h.qround != 2) {
                 if (on_wall) h.qedge = true, h.qround = 2;
                 else h.qobj.y = nobj.y > 0.0 ? e[1] : e[0];
+            } else if (fabs(p.y - e[1]) <= 1e-9 || fabs(p.y - e[0]) <= 1e-9) {
+                // ... and a wall point ON a rim line (random_field:218: seen from inside, y = ymax to the last bit) stands
+                // 1e-16 under or over the cap's plane with its over point: the same noise
+                h.qedge = true;
             }
             break;
         }

@@ -120,7 +120,7 @@ def test_kernels_follow_the_reference_on_the_rooms_corner_line():
 FUZZ = [("random_field:98", 107, 51), ("random_stress:169", 40, 59), ("random_mesh:102", 88, 54), ("random_mesh:130", 79, 78),
         ("random_field:113", 142, 44), ("random_field:134", 156, 53), ("random_stress:39", 62, 64), ("random_stress:162", 152, 73),
         ("random_stress:180", 51, 71), ("random_stress:189", 67, 25), ("random_stress:41", 18, 64), ("random_mesh:107", 33, 69),
-        ("random_mesh:2", 31, 53)]
+        ("random_mesh:2", 31, 53), ("random_field:218", 42, 15)]  # (field:218: a cylinder's wall point on a rim line, qedge)
 
 
 @pytest.mark.parametrize("name,x,y", FUZZ)
