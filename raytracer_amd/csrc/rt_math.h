@@ -42,9 +42,26 @@ RT_HD float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f
 #else
 RT_HD float fast_log2(float x) { return log2f(x); }
 RT_HD float fast_exp2(float x) { return exp2f(x); }
+#ifdef RT_HOST_ULP_NOISE  // tests/cpp/hostsim.cpp only: the host's exact 1/x, sqrt, 1/sqrt moved by -1, 0 or +1 ulp, chosen by a hash
+                          // of the argument's bits and a seed — what the hardware's v_rcp / v_sqrt / v_rsq may do to any decision
+extern unsigned rt_host_ulp_noise;  // 0 = off
+inline float rt_ulp_noise(float r, float x) {
+    if (!rt_host_ulp_noise || !(r == r) || r == INFINITY || r == -INFINITY) return r;
+    unsigned b;
+    __builtin_memcpy(&b, &x, 4);
+    b = (b ^ rt_host_ulp_noise) * 0x9E3779B1u;
+    b ^= b >> 15;
+    const unsigned k = b % 3u;  // 0: as it is, 1: one ulp up, 2: one ulp down
+    return k == 0u ? r : nextafterf(r, k == 1u ? INFINITY : -INFINITY);
+}
+RT_HD float rcp_f(float x) { return rt_ulp_noise(1.0f / x, x); }
+RT_HD float sqrt_f(float x) { return rt_ulp_noise(sqrtf(x), x); }
+RT_HD float rsq_f(float x) { return rt_ulp_noise(1.0f / sqrtf(x), x); }
+#else
 RT_HD float rcp_f(float x) { return 1.0f / x; }
 RT_HD float sqrt_f(float x) { return sqrtf(x); }
 RT_HD float rsq_f(float x) { return 1.0f / sqrtf(x); }
+#endif
 #endif
 RT_HD float div_f(float a, float b) { return a * rcp_f(b); }
 

@@ -15,6 +15,10 @@
 #include <thread>
 #include <vector>
 
+#define RT_HOST_ULP_NOISE 1  // rt_math.h: rcp / sqrt / rsq of this build can be moved by an ulp (hostsim_set_ulp_noise)
+namespace rtk {
+unsigned rt_host_ulp_noise = 0;
+}
 #include "../../raytracer_amd/csrc/rt_pack.h"
 
 using namespace rtk;
@@ -699,6 +703,11 @@ extern "C" int hostsim_tie_audit(const rt_scene_desc* desc, const rt_camera_desc
 
 // Shadow rays of the last renders with the exact chain: out[0] = cast, out[2] = primitives f64 was asked about,
 // out[3] = (node, light) pairs counted again, out[5] / out[6] = of those: because of a quirk-edge hit / a near thing
+// Experiments and tests: move every rcp / sqrt / rsq of the spec by -1, 0 or +1 ulp (a hash of the argument and `seed`
+// chooses; 0 = exact again) — the freedom the hardware's v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 have.  What the near-thing bands
+// of rt_math.h are for: no decision may hang on it.
+extern "C" void hostsim_set_ulp_noise(unsigned seed) { rtk::rt_host_ulp_noise = seed; }
+
 extern "C" void hostsim_shadow_stats(uint64_t* out, int reset) {
     out[0] = g_sh_rays, out[1] = g_sh_unsure, out[2] = g_sh_f64, out[3] = g_sh_redo;
     out[4] = 0, out[5] = g_sh_why_qedge, out[6] = g_sh_why_near;
